@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""ORACLE tooling — generates tests/golden/* by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the authoring container (needs /root/reference; the GPU box has no copy).
+  python oracle/make_golden.py
+
+For each case it
+  1. builds the reference model through ``cvnets.get_model(opts)`` (opts = cvnets.modeling_arguments
+     defaults + the flattened reference YAML) under the torchvision shim,
+  2. loads the deterministic weights of oracle/weights.py, runs a train-mode fwd + label-smoothed
+     CE + bwd and an eval-mode fwd on the seeded input, all fp32 on CPU, dropout p = 0,
+  3. asserts that the oracle restatement (oracle/mobilevit_oracle.py) reproduces the reference
+     (logits, loss, every gradient, BN running stats) to fp32 round-off — this is what pins the
+     oracle — and
+  4. writes the REFERENCE's outputs to tests/golden/<case>.npz (+ the key/shape manifest).
+"""
+import argparse
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from oracle import mobilevit_oracle as orc  # noqa: E402
+from oracle.weights import seeded_input, seeded_labels, seeded_state_dict  # noqa: E402
+
+CASES = [
+    # name, mode, batch, H=W    (BASELINE.json configs[0] and [1] shapes; plus a mid-size case)
+    ("mobilevit_xxs_32_b8", "xx_small", 8, 32),
+    ("mobilevit_s_128_b2", "small", 2, 128),
+    ("mobilevit_s_256_b2", "small", 2, 256),
+    ("mobilevit_s_160_b2", "small", 2, 160),   # VBS resolution (mobilevit.yaml sampler 160..320)
+]
+FULL_GRADS = [
+    "conv_1.block.conv.weight", "conv_1.block.norm.weight", "conv_1.block.norm.bias",
+    "layer_1.0.block.conv_3x3.block.conv.weight",
+    "layer_3.1.global_rep.0.pre_norm_mha.1.qkv_proj.bias",
+    "layer_3.1.global_rep.0.pre_norm_mha.0.weight",
+    "layer_5.1.global_rep.2.pre_norm_ffn.4.bias",
+    "layer_5.1.fusion.block.norm.weight",
+    "classifier.fc.bias",
+]
+
+
+def build_reference_model(mode: str):
+    os.chdir(REF)
+    import cvnets
+    from options.utils import flatten_yaml_as_dict
+
+    parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+    opts = parser.parse_args([])
+    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/classification/imagenet/mobilevit.yaml")))
+    for k, v in cfg.items():
+        if hasattr(opts, k):
+            setattr(opts, k, v)
+    setattr(opts, "dataset.category", "classification")
+    setattr(opts, "dev.device", "cpu")
+    setattr(opts, "model.classification.mit.mode", mode)
+    # parity configuration: dropout off (torch Philox streams are not reproducible across impls)
+    setattr(opts, "model.classification.mit.dropout", 0.0)
+    setattr(opts, "model.classification.mit.attn_dropout", 0.0)
+    setattr(opts, "model.classification.mit.ffn_dropout", 0.0)
+    setattr(opts, "model.classification.classifier_dropout", 0.0)
+    return cvnets.get_model(opts)
+
+
+def run_case(name, mode, batch, res, outdir):
+    torch.manual_seed(0)
+    model = build_reference_model(mode)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)
+    x = seeded_input((batch, 3, res, res), seed=1)
+    y = seeded_labels(batch, 1000, seed=1)
+
+    # --- reference: eval forward, then train step ---
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(x).clone()
+    model.train()
+    taps = {}
+    hooks = []
+    for nm in ("conv_1", "layer_1", "layer_2", "layer_3", "layer_4", "layer_5"):
+        hooks.append(getattr(model, nm).register_forward_hook(
+            lambda m, i, o, nm=nm: taps.__setitem__(nm, o.detach().clone())))
+    logits = model(x)
+    loss = torch.nn.functional.cross_entropy(logits, y, label_smoothing=0.1)
+    model.zero_grad()
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    ref_sd_after = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    # --- oracle restatement on the same weights: must agree to fp32 round-off ---
+    o_eval = orc.mobilevit_forward(sd, x, mode=mode, training=False)
+    o_logits, o_loss, o_grads, o_running = orc.train_step(sd, x, y, mode=mode)
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-30))
+
+    checks = {"logits_eval": rel(o_eval, logits_eval), "logits_train": rel(o_logits, logits.detach()),
+              "loss": abs(float(o_loss) - float(loss))}
+    worst_g = max(rel(o_grads[k], ref_grads[k]) for k in ref_grads)
+    worst_bn = max(rel(v, ref_sd_after[k]) for k, v in o_running.items())
+    checks["grad_worst_rel"] = worst_g
+    checks["bn_running_worst_rel"] = worst_bn
+    print(name, {k: f"{v:.2e}" for k, v in checks.items()})
+    assert checks["logits_eval"] < 1e-5 and checks["logits_train"] < 1e-5, checks
+    assert checks["loss"] < 1e-5 and worst_g < 2e-4 and worst_bn < 1e-5, checks
+    assert set(o_grads) == set(ref_grads)
+
+    names = list(ref_grads.keys())
+    out = {
+        "logits_train": logits.detach().numpy(),
+        "logits_eval": logits_eval.numpy(),
+        "loss": np.float32(loss.item()),
+        "grad_names": np.array(names),
+        "grad_norm": np.array([ref_grads[k].norm().item() for k in names], dtype=np.float64),
+        "grad_sum": np.array([ref_grads[k].double().sum().item() for k in names], dtype=np.float64),
+        "oracle_vs_reference": np.array(json.dumps(checks)),
+    }
+    for k in FULL_GRADS:
+        out["grad::" + k] = ref_grads[k].numpy()
+    for k in ("conv_1.block.norm.running_mean", "conv_1.block.norm.running_var",
+              "layer_3.1.fusion.block.norm.running_mean", "layer_3.1.fusion.block.norm.running_var",
+              "conv_1x1_exp.block.norm.running_var"):
+        out["bn::" + k] = ref_sd_after[k].numpy()
+    for k, t in taps.items():
+        out["tap_stats::" + k] = np.array([t.mean().item(), t.std().item(), t.abs().max().item()], dtype=np.float64)
+        out["tap_slice::" + k] = t[0, : min(8, t.shape[1]), : min(4, t.shape[2]), : min(4, t.shape[3])].numpy()
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    with open(os.path.join(outdir, f"mobilevit_{mode}_keys.json"), "w") as f:
+        json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
+
+
+def mha_cases(outdir):
+    """Pins oracle.multi_head_attention / transformer_encoder against the reference layer incl.
+    masks (the only numerical cross-check the reference's own tests hold for this path:
+    tests/test_multi_head_attn.py:29-121, atol=rtol=1e-3, 3 implementations)."""
+    os.chdir(REF)
+    from cvnets.layers import MultiHeadAttention
+
+    out = {}
+    for idx, (b, s, c, h, causal, kpm) in enumerate([(2, 16, 32, 4, False, False), (3, 21, 48, 4, True, False),
+                                                     (2, 77, 64, 8, True, True), (4, 64, 80, 4, False, False)]):
+        torch.manual_seed(idx)
+        layer = MultiHeadAttention(c, h, attn_dropout=0.0, bias=True).eval()
+        shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+        sd = seeded_state_dict({"mha." + k: s_ for k, s_ in shapes.items()}, seed=idx)
+        layer.load_state_dict({k[4:]: v for k, v in sd.items()})
+        x = seeded_input((b, s, c), seed=100 + idx)
+        am = None
+        if causal:
+            am = torch.full((s, s), float("-inf")).triu(1).unsqueeze(0).expand(b, -1, -1).contiguous()
+        pm = None
+        if kpm:
+            pm = torch.zeros(b, s)
+            pm[:, -5:] = 1
+        with torch.no_grad():
+            ref = layer(x, attn_mask=am, key_padding_mask=pm)
+            ref_pt = layer(x.transpose(0, 1), attn_mask=None if am is None else am[0],
+                           key_padding_mask=None if pm is None else pm.bool(), use_pytorch_mha=True).transpose(0, 1)
+        o = orc.multi_head_attention(sd, "mha", x, h, attn_mask=am, key_padding_mask=pm)
+        err = float((o - ref).abs().max())
+        err_pt = float((ref_pt - ref).abs().max())
+        print(f"mha case {idx}: oracle-vs-ref {err:.2e}  ref_default-vs-ref_pytorch {err_pt:.2e}")
+        assert err < 1e-5 and err_pt < 1e-3
+        out[f"case{idx}_out"] = ref.numpy()
+        out[f"case{idx}_cfg"] = np.array([b, s, c, h, int(causal), int(kpm)])
+    np.savez_compressed(os.path.join(outdir, "mha_cases.npz"), **out)
+
+
+if __name__ == "__main__":
+    outdir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    torch.set_num_threads(8)
+    mha_cases(outdir)
+    for c in CASES:
+        run_case(*c, outdir)
+    print("golden fixtures written to", outdir)

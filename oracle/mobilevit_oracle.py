@@ -1,0 +1,282 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU / fp32 / plain-PyTorch restatement of the CVNets MobileViT hot path (the path named by
+BASELINE.json:north_star).  It is written functionally over a ``state_dict`` (no nn.Module
+tree) so that it shares no code with the product package ``cvnets_amd``.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Parity pinning: ``oracle/make_golden.py`` imports the *reference itself* (``/root/reference``
+through ``oracle/ref_shim``) in the authoring container, checks this restatement against it to
+fp32 round-off on identical weights/inputs (forward, loss, every parameter gradient and BN
+running statistics), and commits the reference's outputs as ``tests/golden/*.npz``.
+``tests/test_oracle_golden.py`` re-checks the restatement against those fixtures everywhere.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# model configuration  (cvnets/models/classification/config/mobilevit.py:11-208)
+# --------------------------------------------------------------------------------------
+def mobilevit_config(mode: str) -> Dict:
+    mode = mode.lower()
+    if mode == "xx_small":
+        exp = 2
+        chans = dict(l1=16, l2=24, l3=48, l4=64, l5=80)
+        tdim = dict(l3=64, l4=80, l5=96)
+    elif mode == "x_small":
+        exp = 4
+        chans = dict(l1=32, l2=48, l3=64, l4=80, l5=96)
+        tdim = dict(l3=96, l4=120, l5=144)
+    elif mode == "small":
+        exp = 4
+        chans = dict(l1=32, l2=64, l3=96, l4=128, l5=160)
+        tdim = dict(l3=144, l4=192, l5=240)
+    else:
+        raise NotImplementedError(mode)
+    return {
+        "exp": exp,
+        "layer1": dict(out=chans["l1"], blocks=1, stride=1),
+        "layer2": dict(out=chans["l2"], blocks=3, stride=2),
+        "layer3": dict(out=chans["l3"], tdim=tdim["l3"], ffn=2 * tdim["l3"], nblk=2),
+        "layer4": dict(out=chans["l4"], tdim=tdim["l4"], ffn=2 * tdim["l4"], nblk=4),
+        "layer5": dict(out=chans["l5"], tdim=tdim["l5"], ffn=2 * tdim["l5"], nblk=3),
+        "last_exp": 4,
+    }
+
+
+def make_divisible(v, divisor=8, min_value=None):
+    # cvnets/utils/math_utils.py (make_divisible), used at cvnets/modules/mobilenetv2.py:176
+    if min_value is None:
+        min_value = divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+# --------------------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------------------
+class BNState:
+    """Collects updated BatchNorm running statistics (train mode) keyed by state_dict prefix."""
+
+    def __init__(self):
+        self.running: Dict[str, Tensor] = {}
+
+
+def conv_bn_act(
+    sd: Dict[str, Tensor],
+    prefix: str,
+    x: Tensor,
+    stride: int = 1,
+    groups: int = 1,
+    dilation: int = 1,
+    use_norm: bool = True,
+    use_act: bool = True,
+    training: bool = True,
+    bn_state: Optional[BNState] = None,
+    momentum: float = 0.1,
+    eps: float = 1e-5,
+) -> Tensor:
+    """ConvLayer2d.forward = Sequential{conv, norm?, act?}  (cvnets/layers/conv_layer.py:254-255).
+
+    conv: nn.Conv2d, padding=(k-1)//2*dilation (conv_layer.py:182-185), bias only without BN
+    (conv_layer.py:157-167).  norm: nn.BatchNorm2d train-mode batch statistics
+    (cvnets/layers/normalization/batch_norm.py:14-49).  act: nn.SiLU (activation/swish.py).
+    """
+    w = sd[prefix + ".block.conv.weight"]
+    b = sd.get(prefix + ".block.conv.bias")
+    k = w.shape[-1]
+    pad = int((k - 1) / 2) * dilation
+    y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dilation, groups=groups)
+    if use_norm:
+        g = sd[prefix + ".block.norm.weight"]
+        be = sd[prefix + ".block.norm.bias"]
+        rm = sd[prefix + ".block.norm.running_mean"].detach().clone()
+        rv = sd[prefix + ".block.norm.running_var"].detach().clone()
+        y = F.batch_norm(y, rm, rv, g, be, training=training, momentum=momentum, eps=eps)
+        if bn_state is not None and training:
+            bn_state.running[prefix + ".block.norm.running_mean"] = rm
+            bn_state.running[prefix + ".block.norm.running_var"] = rv
+    if use_act:
+        y = F.silu(y)
+    return y
+
+
+def inverted_residual(sd, prefix, x, cin, cout, stride, expand, training, bn_state) -> Tensor:
+    """InvertedResidual.forward  (cvnets/modules/mobilenetv2.py:141-235)."""
+    hidden = make_divisible(int(round(cin * expand)), 8)
+    y = x
+    if expand != 1:
+        y = conv_bn_act(sd, prefix + ".block.exp_1x1", y, training=training, bn_state=bn_state)
+    y = conv_bn_act(sd, prefix + ".block.conv_3x3", y, stride=stride, groups=hidden,
+                    training=training, bn_state=bn_state)
+    y = conv_bn_act(sd, prefix + ".block.red_1x1", y, use_act=False, training=training, bn_state=bn_state)
+    if stride == 1 and cin == cout:
+        return x + y
+    return y
+
+
+def layer_norm(sd, prefix, x: Tensor, eps: float = 1e-5) -> Tensor:
+    """LayerNorm.forward  (cvnets/layers/normalization/layer_norm.py:51-72), INCLUDING the
+    channel-first branch taken whenever x.shape[1] == C and ndim > 2 (``(x-u)/(std+eps)``)."""
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    c = w.shape[0]
+    if x.ndim > 2 and x.shape[1] == c:
+        s, u = torch.std_mean(x, dim=1, keepdim=True, unbiased=False)
+        x = (x - u) / (s + eps)
+        shape = [1, c] + [1] * (x.ndim - 2)
+        return torch.addcmul(b.reshape(shape), x, w.reshape(shape))
+    return F.layer_norm(x, (c,), w, b, eps)
+
+
+def multi_head_attention(sd, prefix, x: Tensor, num_heads: int,
+                         attn_mask: Optional[Tensor] = None,
+                         key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """MultiHeadAttention.forward_default, self-attention branch
+    (cvnets/layers/multi_head_attention.py:135-239)."""
+    b, s, c = x.shape
+    hd = c // num_heads
+    qkv = F.linear(x, sd[prefix + ".qkv_proj.weight"], sd.get(prefix + ".qkv_proj.bias"))
+    qkv = qkv.reshape(b, s, 3, num_heads, hd).transpose(1, 3).contiguous()
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    q = q * (hd ** -0.5)
+    attn = torch.matmul(q, k.transpose(-1, -2))
+    if attn_mask is not None:
+        attn = attn + attn_mask.unsqueeze(1)
+    if key_padding_mask is not None:
+        attn = attn.masked_fill(key_padding_mask.unsqueeze(1).unsqueeze(2).to(torch.bool), float("-inf"))
+    attn = torch.softmax(attn.float(), dim=-1).to(attn.dtype)
+    out = torch.matmul(attn, v)
+    out = out.transpose(1, 2).reshape(b, s, -1)
+    return F.linear(out, sd[prefix + ".out_proj.weight"], sd.get(prefix + ".out_proj.bias"))
+
+
+def transformer_encoder(sd, prefix, x: Tensor, num_heads: int, act: str = "swish",
+                        ln_eps: float = 1e-5, attn_mask=None, key_padding_mask=None) -> Tensor:
+    """TransformerEncoder.forward with dropout p=0 / drop_path Identity
+    (cvnets/modules/transformer.py:129-156)."""
+    res = x
+    y = layer_norm(sd, prefix + ".pre_norm_mha.0", x, ln_eps)
+    y = multi_head_attention(sd, prefix + ".pre_norm_mha.1", y, num_heads, attn_mask, key_padding_mask)
+    x = y + res
+    y = layer_norm(sd, prefix + ".pre_norm_ffn.0", x, ln_eps)
+    y = F.linear(y, sd[prefix + ".pre_norm_ffn.1.weight"], sd[prefix + ".pre_norm_ffn.1.bias"])
+    y = F.silu(y) if act == "swish" else F.gelu(y)
+    y = F.linear(y, sd[prefix + ".pre_norm_ffn.4.weight"], sd[prefix + ".pre_norm_ffn.4.bias"])
+    return x + y
+
+
+def unfolding(fm: Tensor, ph: int, pw: int) -> Tuple[Tensor, Dict]:
+    """MobileViTBlock.unfolding  (cvnets/modules/mobilevit_block.py:186-231)."""
+    b, c, oh, ow = fm.shape
+    nh_ = int(math.ceil(oh / ph) * ph)
+    nw_ = int(math.ceil(ow / pw) * pw)
+    interpolate = False
+    if nw_ != ow or nh_ != oh:
+        fm = F.interpolate(fm, size=(nh_, nw_), mode="bilinear", align_corners=False)
+        interpolate = True
+    npw, nph = nw_ // pw, nh_ // ph
+    n = nph * npw
+    p = ph * pw
+    r = fm.reshape(b * c * nph, ph, npw, pw).transpose(1, 2)
+    r = r.reshape(b, c, n, p).transpose(1, 3)
+    patches = r.reshape(b * p, n, -1)
+    info = dict(orig_size=(oh, ow), batch_size=b, interpolate=interpolate, total_patches=n,
+                num_patches_w=npw, num_patches_h=nph)
+    return patches, info
+
+
+def folding(patches: Tensor, info: Dict, ph: int, pw: int) -> Tensor:
+    """MobileViTBlock.folding  (cvnets/modules/mobilevit_block.py:233-267)."""
+    p = ph * pw
+    patches = patches.contiguous().view(info["batch_size"], p, info["total_patches"], -1)
+    b, _, n, c = patches.size()
+    nph, npw = info["num_patches_h"], info["num_patches_w"]
+    patches = patches.transpose(1, 3)
+    fm = patches.reshape(b * c * nph, npw, ph, pw).transpose(1, 2)
+    fm = fm.reshape(b, c, nph * ph, npw * pw)
+    if info["interpolate"]:
+        fm = F.interpolate(fm, size=info["orig_size"], mode="bilinear", align_corners=False)
+    return fm
+
+
+def mobilevit_block(sd, prefix, x: Tensor, n_blocks: int, num_heads: int, training: bool,
+                    bn_state, ph: int = 2, pw: int = 2, taps: Optional[Dict] = None) -> Tensor:
+    """MobileViTBlock.forward_spatial  (cvnets/modules/mobilevit_block.py:269-288)."""
+    res = x
+    fm = conv_bn_act(sd, prefix + ".local_rep.conv_3x3", x, training=training, bn_state=bn_state)
+    fm = conv_bn_act(sd, prefix + ".local_rep.conv_1x1", fm, use_norm=False, use_act=False)
+    patches, info = unfolding(fm, ph, pw)
+    for i in range(n_blocks):
+        patches = transformer_encoder(sd, f"{prefix}.global_rep.{i}", patches, num_heads)
+    patches = layer_norm(sd, f"{prefix}.global_rep.{n_blocks}", patches)
+    if taps is not None:
+        taps[prefix + ".patches"] = patches
+    fm = folding(patches, info, ph, pw)
+    fm = conv_bn_act(sd, prefix + ".conv_proj", fm, training=training, bn_state=bn_state)
+    fm = conv_bn_act(sd, prefix + ".fusion", torch.cat((res, fm), dim=1), training=training, bn_state=bn_state)
+    return fm
+
+
+def mobilevit_forward(sd: Dict[str, Tensor], x: Tensor, mode: str = "small", num_heads: int = 4,
+                      training: bool = True, bn_state: Optional[BNState] = None,
+                      taps: Optional[Dict] = None) -> Tensor:
+    """MobileViT.forward -> BaseImageEncoder.forward_classifier/extract_features
+    (cvnets/models/classification/mobilevit.py:26-125; base_image_encoder.py:261-283);
+    classifier = GlobalPool(mean) -> LinearLayer (mobilevit.py:106-119, global_pool.py:60-71).
+    Dropout layers are p=0 (parity configuration)."""
+    cfg = mobilevit_config(mode)
+    exp = cfg["exp"]
+    x = conv_bn_act(sd, "conv_1", x, stride=2, training=training, bn_state=bn_state)
+    if taps is not None:
+        taps["conv_1"] = x
+    cin = 16
+    for li, name in ((1, "layer1"), (2, "layer2")):
+        c = cfg[name]
+        for i in range(c["blocks"]):
+            st = c["stride"] if i == 0 else 1
+            x = inverted_residual(sd, f"layer_{li}.{i}", x, cin, c["out"], st, exp, training, bn_state)
+            cin = c["out"]
+        if taps is not None:
+            taps[f"layer_{li}"] = x
+    for li, name in ((3, "layer3"), (4, "layer4"), (5, "layer5")):
+        c = cfg[name]
+        x = inverted_residual(sd, f"layer_{li}.0", x, cin, c["out"], 2, exp, training, bn_state)
+        cin = c["out"]
+        x = mobilevit_block(sd, f"layer_{li}.1", x, c["nblk"], num_heads, training, bn_state, taps=taps)
+        if taps is not None:
+            taps[f"layer_{li}"] = x
+    x = conv_bn_act(sd, "conv_1x1_exp", x, training=training, bn_state=bn_state)
+    x = torch.mean(x, dim=[-2, -1])
+    return F.linear(x, sd["classifier.fc.weight"], sd["classifier.fc.bias"])
+
+
+def cross_entropy(logits: Tensor, target: Tensor, label_smoothing: float = 0.1) -> Tensor:
+    """loss_fn/classification/cross_entropy.py:65-92 (training branch: F.cross_entropy with
+    label smoothing, mean reduction)."""
+    return F.cross_entropy(logits, target, label_smoothing=label_smoothing)
+
+
+def train_step(sd: Dict[str, Tensor], x: Tensor, y: Tensor, mode: str = "small",
+               label_smoothing: float = 0.1):
+    """One fwd + loss + bwd of the hot path (engine/training_engine.py:257-287 without the
+    optimizer).  Returns (logits, loss, grads-by-name, updated BN running stats)."""
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
+              for k, v in sd.items()}
+    st = BNState()
+    logits = mobilevit_forward(params, x, mode=mode, training=True, bn_state=st)
+    loss = cross_entropy(logits, y, label_smoothing)
+    names = [k for k, v in params.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [params[k] for k in names])
+    return logits.detach(), loss.detach(), dict(zip(names, grads)), st.running

@@ -1,0 +1,132 @@
+/*
+ * cvnets_hip.h — C ABI of libcvnets_hip.so: the MI355X (gfx950) kernels behind the CVNets backbone
+ * forward/backward hot path (MobileViT block, transformer encoder, conv-BN-act stacks).
+ *
+ * The reference (apple/ml-cvnets) is pure Python and has no FFI; its "operator API" for this path is
+ * the set of torch.nn / torch.nn.functional calls made by cvnets/layers/* and cvnets/modules/*.  Each
+ * entry point below replaces one such call (cited as file:line relative to the reference root).  A
+ * reference maintainer binds them with ctypes; the in-tree binding is
+ * ml-cvnets_amd/cvnets_amd/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless noted; no torch / C++ types cross this boundary;
+ *   - `dtype` selects the storage type of activation tensors: CVH_DT_F32 (0) or CVH_DT_BF16 (1);
+ *     parameters, statistics and parameter gradients are always float32; accumulation is float32;
+ *   - activations are NHWC: a [B,C,H,W] feature map is a row-major [B*H*W][C] matrix, C % 8 == 0;
+ *     token matrices are [rows][C];
+ *   - `stream` is a hipStream_t; kernels are enqueued asynchronously and are hipGraph-capturable
+ *     (no allocation, no synchronisation inside);
+ *   - return value: 0 on success, a positive hipError_t, or a negative code for rejected arguments
+ *     (-1 unknown dtype, -2 unsupported shape/alignment).
+ */
+#ifndef CVNETS_HIP_H_
+#define CVNETS_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVH_DT_F32 0
+#define CVH_DT_BF16 1
+#define CVH_ACT_NONE 0
+#define CVH_ACT_SILU 1 /* nn.SiLU  — cvnets/layers/activation/swish.py */
+#define CVH_ACT_GELU 2 /* nn.GELU (erf) — cvnets/layers/activation/gelu.py:11-18 */
+
+/* ---- layout / dtype plumbing ------------------------------------------------------------------ */
+/* NCHW float32 -> NHWC `dtype`, channels zero-padded to Cp (Cp % 8 == 0).  Replaces the implicit
+ * memory-format conversion of model.to(memory_format=channels_last), main_train.py:72-79. */
+int cvh_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cp, void* stream);
+int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cs, void* stream);
+/* Parameter packing (float32 torch layout [Cout][Cin][KH][KW] -> `dtype`).  mode 0: forward pack
+ * [Cout][KH*KW][pad8(Cin)];  mode 1: dX pack (transposed, taps flipped) [Cin][KH*KW][pad8(Cout)];
+ * mode 2: depthwise [KH*KW][C].  Replaces autocast's per-call weight cast (engine/utils.py:19-36). */
+int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, int Cin, int KHW, int mode, void* stream);
+int cvh_cast_from_f32(int dtype, const float* in, void* out, long long n, void* stream);
+int cvh_cast_to_f32(int dtype, const void* in, float* out, long long n, void* stream);
+
+/* ---- dense conv / linear as implicit GEMM on MFMA ----------------------------------------------- */
+/* out[M=B*Ho*Wo][N] = epilogue( im2col(cat(src1,src2))[M][KH*KW*(C1+C2)] x wgt[N][KH*KW*(C1+C2)]^T )
+ * epilogue order: +bias[N] -> (save_pre) -> act -> (* act'(actgrad_aux)) -> dropout -> +residual -> store
+ *                 -> optional BatchNorm column statistics (sum, sumsq of the stored values) written to
+ *                    stats_part[cvh_conv_gemm_grid_rows(M,N)][2][N].
+ * Replaces nn.Conv2d.forward (cvnets/layers/conv_layer.py:18-66, called at :254-255), F.linear
+ * (cvnets/layers/linear_layer.py:90), torch.cat before the fusion conv (cvnets/modules/mobilevit_block.py:287),
+ * the activation / dropout / residual that follow (cvnets/modules/transformer.py:140-155), and — with the
+ * mode-1 weight pack — their dX backward. */
+int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2, const void* wgt, void* out,
+                  int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                  const float* bias, int act, void* save_pre, const void* actgrad_aux, int actgrad_act,
+                  const void* residual, float drop_p, const unsigned long long* seed, unsigned int stream_id,
+                  float* stats_part, void* stream);
+int cvh_conv_gemm_grid_rows(int M, int N);
+/* dW[N][Cin_real][KH][KW] (float32, torch layout, must be zeroed) += dY[M][N]^T x im2col(src)[M][K].
+ * Replaces the weight-gradient half of Conv2d / Linear backward. */
+int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw,
+                int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                int Cin_real, void* stream);
+
+/* ---- depthwise 3x3 conv (groups == C) ----------------------------------------------------------- */
+/* Replaces nn.Conv2d(groups=C) in InvertedResidual (cvnets/modules/mobilenetv2.py:194-207). */
+int cvh_dwconv_fwd(int dtype, const void* x, const void* wp, void* y, int B, int H, int W, int Ho, int Wo, int C, int K,
+                   int stride, int pad, int dil, float* stats_part, void* stream);
+int cvh_dwconv_rows(int B, int Ho, int Wo, int C); /* rows of stats_part written by cvh_dwconv_fwd */
+int cvh_dwconv_bwd_x(int dtype, const void* dy, const void* wp, void* dx, int B, int H, int W, int Ho, int Wo, int C, int K,
+                     int stride, int pad, int dil, void* stream);
+int cvh_dwconv_bwd_w(int dtype, const void* x, const void* dy, float* part, int B, int H, int W, int Ho, int Wo, int C, int K,
+                     int stride, int pad, int dil, void* stream);
+int cvh_dwconv_bwd_w_rows(int B, int Ho, int Wo, int C); /* rows of part[rows][C*K*K] */
+
+/* ---- BatchNorm2d (train-mode batch statistics) + activation ------------------------------------- */
+/* Replaces nn.BatchNorm2d (cvnets/layers/normalization/batch_norm.py:14-49) followed by nn.SiLU, and the
+ * residual add of InvertedResidual.forward (cvnets/modules/mobilenetv2.py:231-235). */
+int cvh_colreduce_rows(long long rows, int C); /* rows of part[rows][2][C] for the three reducers below */
+int cvh_bn_stats(int dtype, const void* x, long long rows, int C, float* part, void* stream);
+int cvh_bn_finalize(const float* part, int R, int C, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                    void* stream);
+int cvh_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* mean,
+                      float* invstd, float* scale, float* shift, void* stream);
+int cvh_bn_apply(int dtype, const void* x, const float* scale, const float* shift, int act, const void* residual, void* y,
+                 long long rows, int C, void* stream);
+int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, int act, long long rows, int C, float* part, void* stream);
+int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,
+                        int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream);
+int cvh_bn_bwd_apply(int dtype, const void* x, const void* dout, const float* scale, const float* shift, int act, const float* ca,
+                     const float* cb, const float* cc, void* dx, long long rows, int C, void* stream);
+
+/* ---- reductions / small ops --------------------------------------------------------------------- */
+int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, void* stream); /* bias grads */
+int cvh_sum_partials(const float* part, int R, int Wd, float* out, float scale, void* stream);
+/* GlobalPool(mean) cvnets/layers/global_pool.py:60-71 */
+int cvh_pool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, void* stream);
+int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, void* stream);
+/* Dropout cvnets/layers/dropout.py:11-29: counter-based mask = f(*seed, stream_id, element index) */
+int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned int stream_id,
+                void* stream);
+int cvh_seed_advance(unsigned long long* seed, void* stream);
+int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void* stream);
+
+/* ---- LayerNorm over channels -------------------------------------------------------------------- */
+/* Replaces nn.LayerNorm, channel-last branch (cvnets/layers/normalization/layer_norm.py:67-68). */
+int cvh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      long long rows, int C, float eps, void* stream);
+int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                      float* part, long long rows, int C, void* stream);
+int cvh_ln_bwd_rows(long long rows); /* rows of part[rows][2][C] (dgamma | dbeta) */
+
+/* ---- fused multi-head self-attention ------------------------------------------------------------ */
+/* qkv [rows][3*h*c] -> out [rows][h*c]; sequences addressed through the MobileViT unfold map
+ * (ph,pw,n_w,H,W) or contiguously (ph=pw=1,H=1,W=n_w=S).  Replaces MultiHeadAttention.forward_default
+ * lines 148-233 (cvnets/layers/multi_head_attention.py) and MobileViTBlock.unfolding/folding
+ * (cvnets/modules/mobilevit_block.py:186-267).  lse [nseq][h][S] float32 is saved for backward. */
+int cvh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, int nseq, int S, int h, int c,
+                 int ph, int pw, int n_w, int H, int W, float scaling, int causal, void* stream);
+int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                 const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
+                 int causal, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVNETS_HIP_H_ */

@@ -1,0 +1,563 @@
+// Fused multi-head self-attention (flash style) on MFMA, forward + backward, for the token matrices of
+// MobileViT / ViT / CLIP.  The S x S score matrix never reaches HBM (the reference materialises it in
+// fp32 and keeps it for backward: cvnets/layers/multi_head_attention.py:187-233).
+//
+// Layout: qkv is the [rows][3*d] output of the qkv projection (d = heads * c; columns [q | k | v], each
+// split head-major).  A "sequence" is a set of rows given by SeqMap:
+//     row(s, n) = (b*H + nh*ph + i)*W + nw*pw + j,   s = b*ph*pw + i*pw + j,  n = nh*n_w + nw
+// which is exactly MobileViTBlock.unfolding (cvnets/modules/mobilevit_block.py:186-231) applied to an
+// NHWC feature map — so unfold/fold cost nothing.  ph = pw = 1, H = 1, W = n_w = S gives the plain
+// contiguous [B][S][d] case (ViT / CLIP / standalone MultiHeadAttention).
+//
+// One 64-lane wave = one work item (sequence, head, 32-row block); all tiles live in that wave's LDS.
+// Every kernel forms the TRANSPOSED scores S^T = K Q^T, so the MFMA accumulator holds keys along rows and
+// the query along lane&31: the softmax statistics (max / sum / lse / D) are per-lane scalars.
+#include "common.hpp"
+#include "cvnets_hip.h"
+
+struct SeqMap {
+  int ph, pw, n_w, H, W;
+};
+struct AttnParams {
+  const void* qkv;   // T [rows][3d]
+  void* out;         // fwd: T [rows][d]
+  const void* dout;  // bwd: T [rows][d]
+  void* dqkv;        // bwd: T [rows][3d]
+  float* lse;        // [nseq][h][S]
+  float* dsum;       // [nseq][h][S]   D = rowsum(dO * O)
+  const unsigned char* kpm;  // optional key padding mask [nseq][S] (nonzero = masked)
+  int nseq, S, h, c, d;
+  SeqMap map;
+  float scaling;
+  int causal;
+};
+
+__device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
+  const int P = m.ph * m.pw;
+  const int b = s / P, pi = s - b * P;
+  const int i = pi / m.pw, j = pi - i * m.pw;
+  const int nh = n / m.n_w, nw = n - nh * m.n_w;
+  return (b * m.H + nh * m.ph + i) * m.W + nw * m.pw + j;
+}
+
+template <typename T, int VEC> __device__ __forceinline__ void ld_vec(const T* p, float* f) {
+  if (VEC == 4) {
+    v4_unpack(v4_load<T>(p), f);
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = to_f<T>(p[e]);
+  }
+}
+template <typename T, int VEC> __device__ __forceinline__ void st_vec(T* p, const float* f) {
+  if (VEC == 4) {
+    V4<T> v;
+    v4_pack(f, v);
+    v4_store<T>(p, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) p[e] = from_f<T>(f[e]);
+  }
+}
+
+// stage `nrows` rows x CP columns (first c valid, rest zero) of a [rows][ld] global matrix into LDS.
+// rowidx[r] < 0 marks an absent row (zero filled).
+template <typename T, int CP, int VEC>
+__device__ __forceinline__ void stage_rows(T* lds, int pitch, const T* g, int ld, int col0, const int* rowidx, int nrows, int c, float scale,
+                                           int lane) {
+  constexpr int CH = CP / VEC;
+  for (int idx = lane; idx < nrows * CH; idx += 64) {
+    const int r = idx / CH, cc = (idx - r * CH) * VEC;
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+    const int ri = rowidx[r];
+    if (ri >= 0 && cc < c) {
+      ld_vec<T, VEC>(g + (size_t)ri * ld + col0 + cc, f);
+      if (scale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] *= scale;
+      }
+    }
+    st_vec<T, VEC>(lds + r * pitch + cc, f);
+  }
+}
+
+// operand fragment read "down the rows" of a row-major [k][n] LDS tile (the transposed operand):
+// element j = tile[k0 + 8*(lane>>5) + j][col0 + (lane&31)]
+__device__ __forceinline__ Frag<bf16_t> lds_frag_strided(const bf16_t* tile, int pitch, int k0, int col0, int lane) {
+  const uint16_t* p = reinterpret_cast<const uint16_t*>(tile) + (k0 + 8 * (lane >> 5)) * pitch + col0 + (lane & 31);
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)p[(2 * i) * pitch] | ((uint32_t)p[(2 * i + 1) * pitch] << 16);
+  Frag<bf16_t> f;
+  uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
+  f.v = __builtin_bit_cast(bf16x8_t, u);
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag_strided(const float* tile, int pitch, int k0, int col0, int lane) {
+  const float* p = tile + (k0 + 8 * (lane >> 5)) * pitch + col0 + (lane & 31);
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = p[j * pitch];
+  return f;
+}
+
+// write a 32x32 accumulator tile TRANSPOSED into LDS: acc rows (keys) run along the LDS row of column
+// q = lane&31:  dst[(lane&31)*pitch + row0 + acc_row(r)].  Registers 4i..4i+3 are 4 consecutive rows.
+template <typename T>
+__device__ __forceinline__ void store_acc_transposed(T* dst, int pitch, int row0, const float* v /*16*/, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    V4<T> pk;
+    v4_pack(v + 4 * i, pk);
+    v4_store<T>(dst + (lane & 31) * pitch + row0 + 8 * i + 4 * (lane >> 5), pk);
+  }
+}
+// write an accumulator tile in natural orientation: dst[(row0 + acc_row(r))*pitch + col0 + (lane&31)]
+template <typename T>
+__device__ __forceinline__ void store_acc_natural(T* dst, int pitch, int row0, int col0, const float* v, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[(row0 + acc_row(r, lane)) * pitch + col0 + (lane & 31)] = from_f<T>(v[r]);
+}
+
+__device__ __forceinline__ bool key_visible(const AttnParams& p, int s, int key, int q) {
+  if (key >= p.S) return false;
+  if (p.causal && key > q) return false;
+  if (p.kpm && p.kpm[(size_t)s * p.S + key]) return false;
+  return true;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <typename T, int CP, int VEC>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+  constexpr int KB = 64;
+  constexpr int PQ = lds_pitch<T>(CP);
+  constexpr int PP = lds_pitch<T>(KB);
+  constexpr int NFC = CP / 32;
+  __shared__ __attribute__((aligned(16))) T Qs[32 * PQ];
+  __shared__ __attribute__((aligned(16))) T Ks[KB * PQ];
+  __shared__ __attribute__((aligned(16))) T Vs[KB * PQ];
+  __shared__ __attribute__((aligned(16))) T Ps[32 * PP];
+  __shared__ int rq[32];
+  __shared__ int rk[KB];
+
+  const int lane = threadIdx.x;
+  const int nqb = (p.S + 31) / 32;
+  const int qb = blockIdx.x % nqb;
+  const int head = (blockIdx.x / nqb) % p.h;
+  const int s = blockIdx.x / (nqb * p.h);
+  const int q0 = qb * 32;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const int ld = 3 * p.d;
+
+  if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
+  __syncthreads();
+  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane);
+
+  const int my_q = q0 + (lane & 31);
+  float m_run = -1e30f, l_run = 0.f;
+  f32x16_t oacc[NFC];
+#pragma unroll
+  for (int f = 0; f < NFC; ++f) oacc[f] = acc_zero();
+
+  for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
+    if (p.causal && kv0 > q0 + 31) break;  // every key of this tile is in the future of every query of the block
+    __syncthreads();
+    rk[lane] = (kv0 + lane < p.S) ? seq_row(p.map, s, kv0 + lane) : -1;
+    __syncthreads();
+    stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
+    stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
+    __syncthreads();
+
+    // S^T[key][q] = sum_c K[key][c] * Qs[q][c]
+    f32x16_t sacc[KB / 32];
+#pragma unroll
+    for (int f = 0; f < KB / 32; ++f) sacc[f] = acc_zero();
+#pragma unroll
+    for (int kk = 0; kk < CP; kk += 16) {
+      Frag<T> bq = lds_frag(Qs, PQ, 0, kk, lane);
+#pragma unroll
+      for (int f = 0; f < KB / 32; ++f) {
+        Frag<T> ak = lds_frag(Ks, PQ, f * 32, kk, lane);
+        mma32(sacc[f], ak, bq);
+      }
+    }
+    float sv[KB / 32][16];
+    float mx = -1e30f;
+#pragma unroll
+    for (int f = 0; f < KB / 32; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + f * 32 + acc_row(r, lane);
+        float v = key_visible(p, s, key, my_q) ? round_to<T>(sacc[f][r]) : -INFINITY;
+        sv[f][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int f = 0; f < KB / 32; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(sv[f][r] - m_new);
+        sv[f][r] = pv;
+        rs += pv;
+      }
+      store_acc_transposed<T>(Ps, PP, f * 32, sv[f], lane);
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int f = 0; f < NFC; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[f][r] *= alpha;
+    __syncthreads();
+    // O^T[c][q] += sum_key V[key][c] * P^T[key][q]
+#pragma unroll
+    for (int kk = 0; kk < KB; kk += 16) {
+      Frag<T> bp = lds_frag(Ps, PP, 0, kk, lane);
+#pragma unroll
+      for (int f = 0; f < NFC; ++f) {
+        Frag<T> av = lds_frag_strided(Vs, PQ, kk, f * 32, lane);
+        mma32(oacc[f], av, bp);
+      }
+    }
+  }
+
+  if (my_q < p.S) {
+    const float inv_l = 1.0f / l_run;
+    T* out = reinterpret_cast<T*>(p.out);
+    const size_t row = (size_t)rq[lane & 31];
+#pragma unroll
+    for (int f = 0; f < NFC; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cb = f * 32 + 8 * i + 4 * (lane >> 5);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = oacc[f][4 * i + e] * inv_l;
+        if (VEC == 4) {
+          if (cb < p.c) st_vec<T, 4>(out + row * p.d + head * p.c + cb, o);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (cb + e < p.c) out[row * p.d + head * p.c + cb + e] = from_f<T>(o[e]);
+        }
+      }
+    if (lane < 32 && p.lse) p.lse[((size_t)s * p.h + head) * p.S + my_q] = m_run + __logf(l_run);
+  }
+}
+
+// =============================================================================================
+// backward prep: D[s,h,n] = sum_c dO * O
+// =============================================================================================
+template <typename T>
+__global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, AttnParams p) {
+  const size_t total = (size_t)p.nseq * p.h * p.S;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % p.S);
+    const int head = (int)((idx / p.S) % p.h);
+    const int s = (int)(idx / ((size_t)p.S * p.h));
+    const size_t row = (size_t)seq_row(p.map, s, n);
+    float acc = 0.f;
+    for (int cc = 0; cc < p.c; ++cc)
+      acc += to_f<T>(o[row * p.d + head * p.c + cc]) * to_f<T>(dout[row * p.d + head * p.c + cc]);
+    p.dsum[idx] = acc;
+  }
+}
+
+// =============================================================================================
+// backward dQ: one wave per (sequence, head, 32-query block), loops over key tiles
+// =============================================================================================
+template <typename T, int CP, int VEC>
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int KB = 64;
+  constexpr int PQ = lds_pitch<T>(CP);
+  constexpr int PP = lds_pitch<T>(KB);
+  constexpr int NFC = CP / 32;
+  __shared__ __attribute__((aligned(16))) T Qs[32 * PQ];
+  __shared__ __attribute__((aligned(16))) T dOs[32 * PQ];
+  __shared__ __attribute__((aligned(16))) T Ks[KB * PQ];
+  __shared__ __attribute__((aligned(16))) T Vs[KB * PQ];
+  __shared__ __attribute__((aligned(16))) T dSs[32 * PP];
+  __shared__ int rq[32];
+  __shared__ int rk[KB];
+
+  const int lane = threadIdx.x;
+  const int nqb = (p.S + 31) / 32;
+  const int qb = blockIdx.x % nqb;
+  const int head = (blockIdx.x / nqb) % p.h;
+  const int s = blockIdx.x / (nqb * p.h);
+  const int q0 = qb * 32;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* dout = reinterpret_cast<const T*>(p.dout);
+  const int ld = 3 * p.d;
+
+  if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
+  __syncthreads();
+  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane);
+  stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq, 32, p.c, 1.0f, lane);
+
+  const int my_q = q0 + (lane & 31);
+  const bool q_ok = my_q < p.S;
+  const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
+  const float lse = p.lse[sidx], dsum = p.dsum[sidx];
+
+  f32x16_t dqacc[NFC];
+#pragma unroll
+  for (int f = 0; f < NFC; ++f) dqacc[f] = acc_zero();
+
+  for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
+    if (p.causal && kv0 > q0 + 31) break;
+    __syncthreads();
+    rk[lane] = (kv0 + lane < p.S) ? seq_row(p.map, s, kv0 + lane) : -1;
+    __syncthreads();
+    stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
+    stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
+    __syncthreads();
+
+    f32x16_t sacc[KB / 32], dpacc[KB / 32];
+#pragma unroll
+    for (int f = 0; f < KB / 32; ++f) { sacc[f] = acc_zero(); dpacc[f] = acc_zero(); }
+#pragma unroll
+    for (int kk = 0; kk < CP; kk += 16) {
+      Frag<T> bq = lds_frag(Qs, PQ, 0, kk, lane);
+      Frag<T> bd = lds_frag(dOs, PQ, 0, kk, lane);
+#pragma unroll
+      for (int f = 0; f < KB / 32; ++f) {
+        Frag<T> ak = lds_frag(Ks, PQ, f * 32, kk, lane);
+        Frag<T> av = lds_frag(Vs, PQ, f * 32, kk, lane);
+        mma32(sacc[f], ak, bq);   // S^T  = K Q^T
+        mma32(dpacc[f], av, bd);  // dP^T = V dO^T
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < KB / 32; ++f) {
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + f * 32 + acc_row(r, lane);
+        float v = 0.f;
+        if (q_ok && key_visible(p, s, key, my_q)) {
+          const float pv = __expf(round_to<T>(sacc[f][r]) - lse);
+          v = pv * (dpacc[f][r] - dsum);
+        }
+        ds[r] = v;
+      }
+      store_acc_transposed<T>(dSs, PP, f * 32, ds, lane);
+    }
+    __syncthreads();
+    // dQ^T[c][q] += sum_key K[key][c] * dS^T[key][q]
+#pragma unroll
+    for (int kk = 0; kk < KB; kk += 16) {
+      Frag<T> bs = lds_frag(dSs, PP, 0, kk, lane);
+#pragma unroll
+      for (int f = 0; f < NFC; ++f) {
+        Frag<T> ak = lds_frag_strided(Ks, PQ, kk, f * 32, lane);
+        mma32(dqacc[f], ak, bs);
+      }
+    }
+  }
+
+  if (q_ok) {
+    T* dqkv = reinterpret_cast<T*>(p.dqkv);
+    const size_t row = (size_t)rq[lane & 31];
+#pragma unroll
+    for (int f = 0; f < NFC; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cb = f * 32 + 8 * i + 4 * (lane >> 5);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = dqacc[f][4 * i + e] * p.scaling;
+        if (VEC == 4) {
+          if (cb < p.c) st_vec<T, 4>(dqkv + row * ld + head * p.c + cb, o);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (cb + e < p.c) dqkv[row * ld + head * p.c + cb + e] = from_f<T>(o[e]);
+        }
+      }
+  }
+}
+
+// =============================================================================================
+// backward dK, dV: one wave per (sequence, head, 32-key block), loops over 32-query blocks
+// =============================================================================================
+template <typename T, int CP, int VEC>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int QB = 32;
+  constexpr int PQ = lds_pitch<T>(CP);
+  constexpr int PT = lds_pitch<T>(QB);
+  constexpr int NFC = CP / 32;
+  __shared__ __attribute__((aligned(16))) T Ks[32 * PQ];
+  __shared__ __attribute__((aligned(16))) T Vs[32 * PQ];
+  __shared__ __attribute__((aligned(16))) T Qs[QB * PQ];
+  __shared__ __attribute__((aligned(16))) T dOs[QB * PQ];
+  __shared__ __attribute__((aligned(16))) T PTs[32 * PT];
+  __shared__ __attribute__((aligned(16))) T dSTs[32 * PT];
+  __shared__ int rq[QB];
+  __shared__ int rk[32];
+
+  const int lane = threadIdx.x;
+  const int nkb = (p.S + 31) / 32;
+  const int kb = blockIdx.x % nkb;
+  const int head = (blockIdx.x / nkb) % p.h;
+  const int s = blockIdx.x / (nkb * p.h);
+  const int k0 = kb * 32;
+  const T* qkv = reinterpret_cast<const T*>(p.qkv);
+  const T* dout = reinterpret_cast<const T*>(p.dout);
+  const int ld = 3 * p.d;
+
+  if (lane < 32) rk[lane] = (k0 + lane < p.S) ? seq_row(p.map, s, k0 + lane) : -1;
+  __syncthreads();
+  stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, 32, p.c, 1.0f, lane);
+  stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, 32, p.c, 1.0f, lane);
+
+  f32x16_t dkacc[NFC], dvacc[NFC];
+#pragma unroll
+  for (int f = 0; f < NFC; ++f) { dkacc[f] = acc_zero(); dvacc[f] = acc_zero(); }
+
+  for (int qb0 = 0; qb0 < p.S; qb0 += QB) {
+    if (p.causal && qb0 + QB - 1 < k0) continue;  // all queries of this block precede all keys of ours
+    __syncthreads();
+    if (lane < QB) rq[lane] = (qb0 + lane < p.S) ? seq_row(p.map, s, qb0 + lane) : -1;
+    __syncthreads();
+    stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, QB, p.c, p.scaling, lane);
+    stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq, QB, p.c, 1.0f, lane);
+    __syncthreads();
+
+    const int my_q = qb0 + (lane & 31);
+    const bool q_ok = my_q < p.S;
+    const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
+    const float lse = p.lse[sidx], dsum = p.dsum[sidx];
+
+    f32x16_t sacc = acc_zero(), dpacc = acc_zero();
+#pragma unroll
+    for (int kk = 0; kk < CP; kk += 16) {
+      Frag<T> bq = lds_frag(Qs, PQ, 0, kk, lane);
+      Frag<T> bd = lds_frag(dOs, PQ, 0, kk, lane);
+      Frag<T> ak = lds_frag(Ks, PQ, 0, kk, lane);
+      Frag<T> av = lds_frag(Vs, PQ, 0, kk, lane);
+      mma32(sacc, ak, bq);
+      mma32(dpacc, av, bd);
+    }
+    float pt[16], dst[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, lane);
+      float pv = 0.f, dv = 0.f;
+      if (q_ok && key_visible(p, s, key, my_q)) {
+        pv = __expf(round_to<T>(sacc[r]) - lse);
+        dv = pv * (dpacc[r] - dsum);
+      }
+      pt[r] = pv;
+      dst[r] = dv;
+    }
+    store_acc_natural<T>(PTs, PT, 0, 0, pt, lane);    // PTs[key][q]
+    store_acc_natural<T>(dSTs, PT, 0, 0, dst, lane);  // dSTs[key][q]
+    __syncthreads();
+    // dV[key][c] += sum_q P^T[key][q] dO[q][c] ;  dK[key][c] += sum_q dS^T[key][q] Qs[q][c]
+#pragma unroll
+    for (int kk = 0; kk < QB; kk += 16) {
+      Frag<T> ap = lds_frag(PTs, PT, 0, kk, lane);
+      Frag<T> as = lds_frag(dSTs, PT, 0, kk, lane);
+#pragma unroll
+      for (int f = 0; f < NFC; ++f) {
+        Frag<T> bdo = lds_frag_strided(dOs, PQ, kk, f * 32, lane);
+        Frag<T> bqq = lds_frag_strided(Qs, PQ, kk, f * 32, lane);
+        mma32(dvacc[f], ap, bdo);
+        mma32(dkacc[f], as, bqq);
+      }
+    }
+  }
+
+  T* dqkv = reinterpret_cast<T*>(p.dqkv);
+#pragma unroll
+  for (int f = 0; f < NFC; ++f) {
+    const int col = f * 32 + (lane & 31);
+    if (col >= p.c) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = acc_row(r, lane);
+      if (k0 + kr < p.S) {
+        const size_t row = (size_t)rk[kr];
+        dqkv[row * ld + p.d + head * p.c + col] = from_f<T>(dkacc[f][r]);
+        dqkv[row * ld + 2 * p.d + head * p.c + col] = from_f<T>(dvacc[f][r]);
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+static AttnParams make_params(const void* qkv, void* out, const void* dout, void* dqkv, float* lse, float* dsum, const unsigned char* kpm,
+                              int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling, int causal) {
+  AttnParams p;
+  p.qkv = qkv; p.out = out; p.dout = dout; p.dqkv = dqkv; p.lse = lse; p.dsum = dsum; p.kpm = kpm;
+  p.nseq = nseq; p.S = S; p.h = h; p.c = c; p.d = h * c;
+  p.map.ph = ph; p.map.pw = pw; p.map.n_w = n_w; p.map.H = H; p.map.W = W;
+  p.scaling = scaling; p.causal = causal;
+  return p;
+}
+
+#define ATTN_DISPATCH(KERNEL, GRID)                                                                              \
+  do {                                                                                                           \
+    const int vec = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);                                                   \
+    const bool cp32 = c <= 32;                                                                                   \
+    if (dtype == CVH_DT_BF16) {                                                                                  \
+      if (cp32) { if (vec == 4) hipLaunchKernelGGL((KERNEL<bf16_t, 32, 4>), dim3(GRID), dim3(64), 0, st, p);     \
+                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<bf16_t, 32, 2>), dim3(GRID), dim3(64), 0, st, p); \
+                  else hipLaunchKernelGGL((KERNEL<bf16_t, 32, 1>), dim3(GRID), dim3(64), 0, st, p); }            \
+      else      { if (vec == 4) hipLaunchKernelGGL((KERNEL<bf16_t, 64, 4>), dim3(GRID), dim3(64), 0, st, p);     \
+                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<bf16_t, 64, 2>), dim3(GRID), dim3(64), 0, st, p); \
+                  else hipLaunchKernelGGL((KERNEL<bf16_t, 64, 1>), dim3(GRID), dim3(64), 0, st, p); }            \
+    } else if (dtype == CVH_DT_F32) {                                                                            \
+      if (cp32) { if (vec == 4) hipLaunchKernelGGL((KERNEL<float, 32, 4>), dim3(GRID), dim3(64), 0, st, p);      \
+                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<float, 32, 2>), dim3(GRID), dim3(64), 0, st, p);  \
+                  else hipLaunchKernelGGL((KERNEL<float, 32, 1>), dim3(GRID), dim3(64), 0, st, p); }             \
+      else      { if (vec == 4) hipLaunchKernelGGL((KERNEL<float, 64, 4>), dim3(GRID), dim3(64), 0, st, p);      \
+                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<float, 64, 2>), dim3(GRID), dim3(64), 0, st, p);  \
+                  else hipLaunchKernelGGL((KERNEL<float, 64, 1>), dim3(GRID), dim3(64), 0, st, p); }             \
+    } else return -1;                                                                                            \
+  } while (0)
+
+extern "C" int cvh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, int nseq, int S, int h, int c,
+                            int ph, int pw, int n_w, int H, int W, float scaling, int causal, void* stream) {
+  if (c > 64 || c <= 0 || S <= 0) return -2;
+  AttnParams p = make_params(qkv, out, nullptr, nullptr, lse, nullptr, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = nseq * h * ((S + 31) / 32);
+  ATTN_DISPATCH(attn_fwd_kernel, grid);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                            const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
+                            int causal, void* stream) {
+  if (c > 64 || c <= 0 || S <= 0) return -2;
+  AttnParams p = make_params(qkv, nullptr, dout, dqkv, const_cast<float*>(lse), dsum, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    size_t total = (size_t)nseq * h * S;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, p);
+    else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)out, (const float*)dout, p);
+    else return -1;
+    CVH_CHECK_LAUNCH();
+  }
+  const int grid = nseq * h * ((S + 31) / 32);
+  ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
+  CVH_CHECK_LAUNCH();
+  ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,230 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of the CVNets hot path.
+// Wave = 64 lanes everywhere.  Storage type T is float (parity mode) or bf16_t (bf16 mode);
+// all arithmetic accumulates in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#define CVH_DT_F32 0
+#define CVH_DT_BF16 1
+
+#define CVH_ACT_NONE 0
+#define CVH_ACT_SILU 1
+#define CVH_ACT_GELU 2
+
+struct bf16_t {
+  uint16_t v;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                             // round-to-nearest-even
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x.v); }
+template <typename T> __device__ __forceinline__ T from_f(float f);
+template <> __device__ __forceinline__ float from_f<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float f) {
+  bf16_t r;
+  r.v = f2bf(f);
+  return r;
+}
+// value as it will read back after being stored as T
+template <typename T> __device__ __forceinline__ float round_to(float f) { return to_f<T>(from_f<T>(f)); }
+
+// ---------------------------------------------------------------------------------------------
+// 8-element and 4-element vectors of T (16 B / 8 B for bf16, 32 B / 16 B for f32)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct V8;
+template <> struct V8<bf16_t> {
+  uint4 d;
+};
+template <> struct V8<float> {
+  float4 a, b;
+};
+template <typename T> struct V4;
+template <> struct V4<bf16_t> {
+  uint2 d;
+};
+template <> struct V4<float> {
+  float4 a;
+};
+
+template <typename T> __device__ __forceinline__ V8<T> v8_zero();
+template <> __device__ __forceinline__ V8<bf16_t> v8_zero<bf16_t>() {
+  V8<bf16_t> r;
+  r.d = make_uint4(0, 0, 0, 0);
+  return r;
+}
+template <> __device__ __forceinline__ V8<float> v8_zero<float>() {
+  V8<float> r;
+  r.a = make_float4(0, 0, 0, 0);
+  r.b = r.a;
+  return r;
+}
+template <typename T> __device__ __forceinline__ V8<T> v8_load(const T* p) { return *reinterpret_cast<const V8<T>*>(p); }
+template <typename T> __device__ __forceinline__ void v8_store(T* p, const V8<T>& v) { *reinterpret_cast<V8<T>*>(p) = v; }
+template <typename T> __device__ __forceinline__ V4<T> v4_load(const T* p) { return *reinterpret_cast<const V4<T>*>(p); }
+template <typename T> __device__ __forceinline__ void v4_store(T* p, const V4<T>& v) { *reinterpret_cast<V4<T>*>(p) = v; }
+
+__device__ __forceinline__ void v8_unpack(const V8<bf16_t>& v, float* f) {
+  const uint32_t w[4] = {v.d.x, v.d.y, v.d.z, v.d.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void v8_unpack(const V8<float>& v, float* f) {
+  f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w;
+  f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+}
+__device__ __forceinline__ void v8_pack(const float* f, V8<bf16_t>& v) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(f[2 * i]) | ((uint32_t)f2bf(f[2 * i + 1]) << 16);
+  v.d = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void v8_pack(const float* f, V8<float>& v) {
+  v.a = make_float4(f[0], f[1], f[2], f[3]);
+  v.b = make_float4(f[4], f[5], f[6], f[7]);
+}
+__device__ __forceinline__ void v4_unpack(const V4<bf16_t>& v, float* f) {
+  f[0] = __uint_as_float(v.d.x << 16); f[1] = __uint_as_float(v.d.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.d.y << 16); f[3] = __uint_as_float(v.d.y & 0xffff0000u);
+}
+__device__ __forceinline__ void v4_unpack(const V4<float>& v, float* f) {
+  f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w;
+}
+__device__ __forceinline__ void v4_pack(const float* f, V4<bf16_t>& v) {
+  v.d.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  v.d.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+}
+__device__ __forceinline__ void v4_pack(const float* f, V4<float>& v) { v.a = make_float4(f[0], f[1], f[2], f[3]); }
+
+// ---------------------------------------------------------------------------------------------
+// activations (fp32 math)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  if (act == CVH_ACT_SILU) return x * sigmoidf_(x);
+  if (act == CVH_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));  // exact erf GELU
+  return x;
+}
+__device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
+  if (act == CVH_ACT_SILU) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+  }
+  if (act == CVH_ACT_GELU) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+  }
+  return 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG for dropout: keep-mask is a pure function of (seed, stream id, element index)
+// so backward regenerates the identical mask without storing it.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t stream, uint64_t idx, float p, float inv_keep) {
+  uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + stream * 0x9e3779b9u + (uint32_t)seed));
+  h = mix32(h ^ (uint32_t)(seed >> 32));
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA 32x32 tiles.  Operand fragment = 8 consecutive K elements per lane:
+//   A: lane l holds A[row = l & 31][k = 8*(l >> 5) + 0..7]    (per 16-wide K step)
+//   B: lane l holds B[col = l & 31][k = 8*(l >> 5) + 0..7]    (B stored [N][K], K contiguous)
+//   C/D: acc[r] of lane l is D[row = (r & 3) + 8*(r >> 2) + 4*(l >> 5)][col = l & 31]
+// bf16: one v_mfma_f32_32x32x16_bf16; f32: eight v_mfma_f32_32x32x2_f32 (exact f32 fma chain) that
+// consume the same 8-per-lane fragment (k-pairs {j, 8+j}); A and B use the same k assignment so the
+// contraction is identical.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  bf16x8_t v;
+};
+template <> struct Frag<float> {
+  float v[8];
+};
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// read the fragment for rows [row0, row0+32) and K offset k0 from an LDS tile with `pitch` elements per row
+__device__ __forceinline__ Frag<bf16_t> lds_frag(const bf16_t* tile, int pitch, int row0, int k0, int lane) {
+  const bf16_t* p = tile + (row0 + (lane & 31)) * pitch + k0 + 8 * (lane >> 5);
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8_t*>(p);
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag(const float* tile, int pitch, int row0, int k0, int lane) {
+  const float* p = tile + (row0 + (lane & 31)) * pitch + k0 + 8 * (lane >> 5);
+  Frag<float> f;
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+__device__ __forceinline__ void mma32(f32x16_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16_t& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t acc_zero() {
+  f32x16_t z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+// LDS row pitch (elements) for a tile with `k` K-elements per row: +16 B pad makes the 16 rows of a
+// ds_read_b128 lane group land on distinct 4-bank slots (pitch/4 dwords odd multiple of 4).
+template <typename T> __host__ __device__ constexpr int lds_pitch(int k) { return k + 16 / (int)sizeof(T); }
+
+// compile-time loop: body receives std::integral_constant<int, I> (keeps register arrays statically indexed)
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+#define CVH_CHECK_LAUNCH()                         \
+  do {                                             \
+    hipError_t e_ = hipGetLastError();             \
+    if (e_ != hipSuccess) return (int)e_;          \
+  } while (0)

@@ -1,0 +1,544 @@
+// HBM-bound NHWC kernels: layout/dtype conversion, weight packing, BatchNorm (train-mode statistics,
+// apply, backward), column reductions, global pooling, dropout backward.
+// All are streaming kernels: 16 B (bf16) / 32 B (f32) per lane, channel index = fastest dimension.
+//
+// Replaces (reference, ATen calls): nn.BatchNorm2d cvnets/layers/normalization/batch_norm.py:14-49,
+// nn.SiLU cvnets/layers/activation/swish.py, GlobalPool cvnets/layers/global_pool.py:60-71,
+// Dropout cvnets/layers/dropout.py:11-29 and their autograd backward.
+#include "common.hpp"
+#include "cvnets_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// NCHW f32  ->  NHWC T (channels zero-padded to Cp, Cp % 8 == 0)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int H, int W, int Cp) {
+  const size_t npix = (size_t)B * H * W;
+  const int cgs = Cp / 8;
+  const size_t total = npix * cgs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = idx % npix;
+    const int cg = (int)(idx / npix);
+    const size_t hw = (size_t)H * W;
+    const size_t b = pix / hw, rem = pix - b * hw;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = cg * 8 + j;
+      f[j] = c < C ? in[(b * C + c) * hw + rem] : 0.f;
+    }
+    V8<T> v;
+    v8_pack(f, v);
+    v8_store<T>(out + pix * Cp + cg * 8, v);
+  }
+}
+
+// NHWC T -> NCHW f32 (first C of Cs channels)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W, int Cs) {
+  const size_t hw = (size_t)H * W;
+  const size_t total = (size_t)B * C * hw;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t rem = idx % hw;
+    const size_t bc = idx / hw;
+    const size_t b = bc / C, c = bc - b * C;
+    out[idx] = to_f<T>(in[(b * hw + rem) * Cs + c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: torch [Cout][Cin][KH][KW] f32  ->  T
+//   mode 0 (forward):   out[n][tap*Cp + c]            = w[n][c][tap]          rows = Cout, Cp = pad8(Cin)
+//   mode 1 (dX, s=1):   out[c][tap*Np + n]            = w[n][c][KH*KW-1-tap]  rows = Cin (transposed, taps flipped), Np = pad8(Cout)
+//   mode 2 (depthwise): out[tap*C + c]                = w[c][0][tap]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void weight_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KHW, int Cp, int Np,
+                                   int mode) {
+  size_t total;
+  if (mode == 0) total = (size_t)Cout * KHW * Cp;
+  else if (mode == 1) total = (size_t)Cin * KHW * Np;
+  else total = (size_t)KHW * Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (mode == 0) {
+      int c = (int)(idx % Cp);
+      size_t t = idx / Cp;
+      int tap = (int)(t % KHW);
+      int n = (int)(t / KHW);
+      if (c < Cin) v = w[((size_t)n * Cin + c) * KHW + tap];
+    } else if (mode == 1) {
+      int n = (int)(idx % Np);
+      size_t t = idx / Np;
+      int tap = (int)(t % KHW);
+      int c = (int)(t / KHW);
+      if (n < Cout) v = w[((size_t)n * Cin + c) * KHW + (KHW - 1 - tap)];
+    } else {
+      int c = (int)(idx % Cout);
+      int tap = (int)(idx / Cout);
+      v = w[(size_t)c * KHW + tap];
+    }
+    out[idx] = from_f<T>(v);
+  }
+}
+
+// f32 vector -> T (bias etc.), or T -> f32
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = from_f<T>(in[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = to_f<T>(in[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic column reduction over a [rows][C] NHWC matrix.  MODE selects what is summed:
+//   0: (x, x*x)                      BatchNorm forward statistics
+//   1: (dz, dz*xhat)                 BatchNorm backward: dz = dout * act'(x*scale+shift), xhat = (x-mean)*invstd
+//   2: (x, 0)                        plain column sum (bias gradients)
+// Block = 256 threads = (C/8 channel groups) x (row lanes).  Writes part[block][2][C].
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, int act, size_t rows, int C, float* __restrict__ part) {
+  __shared__ float red[4096];
+  const int cgs = C / 8;
+  const int RL = 256 / cgs;
+  const int ci = threadIdx.x % cgs;
+  const int rl = threadIdx.x / cgs;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  float sc[8], sh[8], mu[8], is[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = scale[ci * 8 + j]; sh[j] = shift[ci * 8 + j]; mu[j] = mean[ci * 8 + j]; is[j] = invstd[ci * 8 + j];
+    }
+  }
+  if (rl < RL) {
+    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
+      float xf[8];
+      v8_unpack(v8_load<T>(x + r * C + ci * 8), xf);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += xf[j]; s2[j] += xf[j] * xf[j]; }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1[j] += xf[j];
+      } else {
+        float df[8];
+        v8_unpack(v8_load<T>(dout + r * C + ci * 8), df);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = xf[j] * sc[j] + sh[j];
+          float dz = df[j] * act_grad(z, act);
+          s1[j] += dz;
+          s2[j] += dz * (xf[j] - mu[j]) * is[j];
+        }
+      }
+    }
+  }
+  // reduce over row lanes through LDS: red[rl][2][C]
+  if (rl < RL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(rl * 2 + 0) * C + ci * 8 + j] = s1[j];
+      red[(rl * 2 + 1) * C + ci * 8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float s = 0.f;
+    for (int l = 0; l < RL; ++l) s += red[l * 2 * C + i];
+    part[(size_t)blockIdx.x * 2 * C + i] = s;
+  }
+}
+
+// sum partial rows: part[R][W] -> out[W]  (f64 accumulation); block = 64 columns x 16 row lanes
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int R, int stride, int Wd, float* __restrict__ out, float scale) {
+  __shared__ double red[16][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  double s = 0.0;
+  if (col < Wd)
+    for (int r = rl; r < R; r += 16) s += (double)part[(size_t)r * stride + col];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < Wd) {
+    double t = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x & 63];
+    out[col] = (float)(t * (double)scale);
+  }
+}
+
+// BatchNorm forward finalize: part[R][2][C] (sum, sumsq) -> mean, invstd, scale, shift; running-stat update.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int R, int C, double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[16][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = rl; r < R; r += 16) {
+      a += (double)part[(size_t)r * 2 * C + c];
+      b += (double)part[(size_t)r * 2 * C + C + c];
+    }
+  red[rl][0][threadIdx.x & 63] = a;
+  red[rl][1][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { s1 += red[l][0][threadIdx.x & 63]; s2 += red[l][1][threadIdx.x & 63]; }
+    double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    scale[c] = g * is;
+    shift[c] = be - (float)mu * g * is;
+    if (running_mean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// eval-mode BatchNorm: scale/shift from running statistics
+__global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                     const float* __restrict__ rv, float eps, int C, float* __restrict__ mean, float* __restrict__ invstd,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float is = 1.0f / sqrtf(rv[c] + eps);
+    float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    mean[c] = rm[c];
+    invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = be - rm[c] * g * is;
+  }
+}
+
+// y = act(x*scale[c] + shift[c]) (+ residual)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                       const T* __restrict__ residual, T* __restrict__ y, size_t rows, int C) {
+  const int cgs = C / 8;
+  const size_t total = rows * cgs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % cgs) * 8;
+    float f[8];
+    v8_unpack(v8_load<T>(x + idx * 8), f);
+    const float4 sa = *reinterpret_cast<const float4*>(scale + c0), sb = *reinterpret_cast<const float4*>(scale + c0 + 4);
+    const float4 ha = *reinterpret_cast<const float4*>(shift + c0), hb = *reinterpret_cast<const float4*>(shift + c0 + 4);
+    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = act_fwd(f[j] * sc[j] + sh[j], act);
+    if (residual) {
+      float rf[8];
+      v8_unpack(v8_load<T>(residual + idx * 8), rf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += rf[j];
+    }
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(y + idx * 8, o);
+  }
+}
+
+// BatchNorm backward finalize: part[R][2][C] = (sum dz, sum dz*xhat)  ->  dgamma, dbeta and the per-channel
+// coefficients of  dx = ca*dz + cb*x + cc   (train mode; eval mode: ca = gamma*invstd, cb = cc = 0)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, double count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd, int training,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ca,
+                                                               float* __restrict__ cb, float* __restrict__ cc) {
+  __shared__ double red[16][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = rl; r < R; r += 16) {
+      a += (double)part[(size_t)r * 2 * C + c];
+      b += (double)part[(size_t)r * 2 * C + C + c];
+    }
+  red[rl][0][threadIdx.x & 63] = a;
+  red[rl][1][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { s1 += red[l][0][threadIdx.x & 63]; s2 += red[l][1][threadIdx.x & 63]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    const double g = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
+    if (training) {
+      ca[c] = (float)(g * is);
+      cb[c] = (float)(-g * is * is * s2 / count);
+      cc[c] = (float)(-g * is * s1 / count + g * is * is * mu * s2 / count);
+    } else {
+      ca[c] = (float)(g * is);
+      cb[c] = 0.f;
+      cc[c] = 0.f;
+    }
+  }
+}
+
+// dx = ca[c]*dz + cb[c]*x + cc[c],  dz = dout * act'(x*scale + shift)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act, const float* __restrict__ ca,
+                                                           const float* __restrict__ cb, const float* __restrict__ cc, T* __restrict__ dx,
+                                                           size_t rows, int C) {
+  const int cgs = C / 8;
+  const size_t total = rows * cgs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % cgs) * 8;
+    float xf[8], df[8], o[8];
+    v8_unpack(v8_load<T>(x + idx * 8), xf);
+    v8_unpack(v8_load<T>(dout + idx * 8), df);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float z = xf[j] * scale[c] + shift[c];
+      float dz = df[j] * act_grad(z, act);
+      o[j] = ca[c] * dz + cb[c] * xf[j] + cc[c];
+    }
+    V8<T> ov;
+    v8_pack(o, ov);
+    v8_store<T>(dx + idx * 8, ov);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// global mean pooling over HW:  x [B][HW][C] -> y [B][C] ; backward broadcasts dy / HW
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int HW, int C) {
+  const int cgs = C / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * cgs) return;
+  const int b = idx / cgs, cg = idx - b * cgs;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < HW; ++i) {
+    float f[8];
+    v8_unpack(v8_load<T>(x + ((size_t)b * HW + i) * C + cg * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += f[j];
+  }
+  const float inv = 1.0f / (float)HW;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] *= inv;
+  V8<T> o;
+  v8_pack(s, o);
+  v8_store<T>(y + (size_t)b * C + cg * 8, o);
+}
+template <typename T>
+__global__ void pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int HW, int C) {
+  const int cgs = C / 8;
+  const size_t total = (size_t)B * HW * cgs;
+  const float inv = 1.0f / (float)HW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cgs);
+    const size_t b = idx / ((size_t)HW * cgs);
+    float f[8];
+    v8_unpack(v8_load<T>(dy + b * C + cg * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= inv;
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(dx + idx * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout (standalone form) : y = x * mask/(1-p)  — same counter-based mask as the GEMM epilogue
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, float p, const unsigned long long* __restrict__ seedp,
+                               unsigned int stream_id) {
+  const unsigned long long seed = *seedp;
+  const float inv_keep = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = from_f<T>(to_f<T>(x[i]) * dropout_scale(seed, stream_id, i, p, inv_keep));
+}
+
+// elementwise a + b (residual adds outside GEMM epilogues)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    v8_unpack(v8_load<T>(a + i * 8), fa);
+    v8_unpack(v8_load<T>(b + i * 8), fb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+    V8<T> o;
+    v8_pack(fa, o);
+    v8_store<T>(y + i * 8, o);
+  }
+}
+
+__global__ void seed_advance_kernel(unsigned long long* seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+static inline int grid_for(size_t total, int block, int cap = 4096) {
+  size_t g = (total + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define DISPATCH_T(dtype, ...)                         \
+  if ((dtype) == CVH_DT_BF16) { using T = bf16_t; __VA_ARGS__ } \
+  else if ((dtype) == CVH_DT_F32) { using T = float; __VA_ARGS__ } \
+  else return -1;
+
+extern "C" int cvh_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cp, void* stream) {
+  if (Cp % 8 || Cp < C) return -2;
+  size_t total = (size_t)B * H * W * (Cp / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, (T*)out, B, C, H, W, Cp);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cs, void* stream) {
+  size_t total = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)in, out, B, C, H, W, Cs);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, int Cin, int KHW, int mode, void* stream) {
+  const int Cp = (Cin + 7) / 8 * 8, Np = (Cout + 7) / 8 * 8;
+  size_t total = mode == 0 ? (size_t)Cout * KHW * Cp : (mode == 1 ? (size_t)Cin * KHW * Np : (size_t)KHW * Cout);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Cout, Cin, KHW, Cp, Np, mode);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_cast_from_f32(int dtype, const float* in, void* out, long long n, void* stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((cast_from_f32_kernel<T>), dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, in, (T*)out, (size_t)n);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_cast_to_f32(int dtype, const void* in, float* out, long long n, void* stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((cast_to_f32_kernel<T>), dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)in, out, (size_t)n);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int cvh_colreduce_rows(long long rows, int C) {
+  // number of partial rows (gridDim.x) the column-reduction kernels write
+  if (C % 8 || C > 2048 || C <= 0) return -2;
+  const int RL = 256 / (C / 8);
+  long long g = (rows + (long long)RL * 8 - 1) / ((long long)RL * 8);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int cvh_bn_stats(int dtype, const void* x, long long rows, int C, float* part, void* stream) {
+  int g = cvh_colreduce_rows(rows, C);
+  if (g < 0) return g;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 0>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, void* stream) {
+  int g = cvh_colreduce_rows(rows, C);
+  if (g < 0) return g;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part);)
+  CVH_CHECK_LAUNCH();
+  // the plain sums live in the first C entries of each 2C-wide partial row
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, g, 2 * C, C, out, scale);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_sum_partials(const float* part, int R, int Wd, float* out, float scale, void* stream) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((Wd + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, R, Wd, Wd, out, scale);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_bn_finalize(const float* part, int R, int C, double count, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                               void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean, invstd, scale, shift);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* mean,
+                                 float* invstd, float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C, mean, invstd, scale, shift);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_bn_apply(int dtype, const void* x, const float* scale, const float* shift, int act, const void* residual, void* y,
+                            long long rows, int C, void* stream) {
+  if (C % 8) return -2;
+  size_t total = (size_t)rows * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, act, (const T*)residual, (T*)y, (size_t)rows, C);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, int act, long long rows, int C, float* part, void* stream) {
+  int g = cvh_colreduce_rows(rows, C);
+  if (g < 0) return g;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 1>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dout, scale, shift, mean, invstd, act, (size_t)rows, C, part);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,
+                                   int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, mean, invstd, training,
+                     dgamma, dbeta, ca, cb, cc);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_bn_bwd_apply(int dtype, const void* x, const void* dout, const float* scale, const float* shift, int act, const float* ca,
+                                const float* cb, const float* cc, void* dx, long long rows, int C, void* stream) {
+  if (C % 8) return -2;
+  size_t total = (size_t)rows * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dout, scale, shift, act, ca, cb, cc, (T*)dx, (size_t)rows, C);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_pool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, void* stream) {
+  if (C % 8) return -2;
+  int total = B * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((pool_fwd_kernel<T>), dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, HW, C);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, void* stream) {
+  if (C % 8) return -2;
+  size_t total = (size_t)B * HW * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, HW, C);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned int stream_id,
+                           void* stream) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (size_t)n, p, seed, stream_id);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void* stream) {
+  if (n % 8) return -2;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for((size_t)n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n / 8);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_seed_advance(unsigned long long* seed, void* stream) {
+  hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,476 @@
+// Implicit-GEMM convolution / linear kernels on MFMA (gfx950), NHWC activations.
+//
+//   conv_gemm  (NT):  out[m, n] = epilogue( sum_k A(m, k) * Wp[n, k] )
+//        m = (b, ho, wo) output pixel, k = (kh, kw, c) with c contiguous (NHWC), Wp = packed weights
+//        [N][KH*KW*Cin].  Pointwise conv / nn.Linear are the KH = KW = 1 special case (A = x[m, :]).
+//        A can be the channel-concat of two tensors (MobileViT fusion conv reads cat(res, fm) without
+//        materialising it).  Used for: forward of every dense conv / linear, and for dX of stride-1
+//        convs / linears with the flipped-transposed weight pack.
+//   gemm_tn  (dW):    dW[n, k] += sum_m dY[m, n] * A(m, k)      (reduction over pixels, split over m)
+//
+// Replaces (reference, ATen calls): nn.Conv2d.forward  cvnets/layers/conv_layer.py:18-66,254-255;
+// F.linear cvnets/layers/linear_layer.py:90; and their autograd backward.
+#include "common.hpp"
+#include "cvnets_hip.h"
+
+struct ConvGemmParams {
+  const void* src1;
+  const void* src2;
+  int C1, C2;
+  const void* wgt;
+  void* out;
+  int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
+  int M, N, Ktot;
+  const float* bias;
+  int act;
+  void* save_pre;
+  const void* actgrad_aux;
+  int actgrad_act;
+  const void* residual;
+  float drop_p;
+  const unsigned long long* seed;
+  unsigned int stream_id;
+  float* stats_part;
+  int m_tiles;
+};
+
+template <typename T, int WM, int WN, int NF, int BK>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
+  constexpr int BM = 32 * WM;
+  constexpr int BN = 32 * NF * WN;
+  constexpr int CPR = BK / 8;
+  constexpr int PITCH = lds_pitch<T>(BK);
+  constexpr int A_IT = (BM * CPR + 255) / 256;
+  constexpr int B_IT = (BN * CPR + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Bs = As + BM * PITCH;
+  float* red = reinterpret_cast<float*>(Bs + BN * PITCH);  // [WM][2][BN] column partial sums
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WN;
+  const int wave_n = wave % WN;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = p.C1 + p.C2;
+  const T* __restrict__ src1 = reinterpret_cast<const T*>(p.src1);
+  const T* __restrict__ src2 = reinterpret_cast<const T*>(p.src2);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
+  T* __restrict__ out = reinterpret_cast<T*>(p.out);
+
+  const int ccol = tid % CPR;  // this thread's 8-wide K chunk column inside a tile row (same for all its chunks)
+  const bool pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
+
+  // running column statistics (for BatchNorm) across all M tiles of this block
+  float cs1[NF], cs2[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) cs1[f] = cs2[f] = 0.f;
+
+  unsigned long long seed = 0;
+  if (p.drop_p > 0.f) seed = *p.seed;
+  const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+
+  for (int tile_m = blockIdx.x; tile_m < p.m_tiles; tile_m += gridDim.x) {
+    const int m0 = tile_m * BM;
+
+    // ---- per-chunk row decode (fixed over the K loop) ----
+    int a_row[A_IT];
+    int a_b[A_IT], a_h[A_IT], a_w[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int q = tid + i * 256;
+      int r = q / CPR;
+      a_row[i] = r;
+      int m = m0 + r;
+      a_ok[i] = (q < BM * CPR) && (m < p.M);
+      if (pointwise) {
+        a_b[i] = 0; a_h[i] = 0; a_w[i] = m;  // linear pixel index
+      } else {
+        int hw = p.Ho * p.Wo;
+        int b = m / hw;
+        int rem = m - b * hw;
+        int ho = rem / p.Wo;
+        int wo = rem - ho * p.Wo;
+        a_b[i] = b; a_h[i] = ho * p.stride - p.pad; a_w[i] = wo * p.stride - p.pad;
+      }
+    }
+
+    f32x16_t acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = acc_zero();
+
+    V8<T> ra[A_IT], rb[B_IT];
+
+    auto load_tiles = [&](int k0) {
+      const int k = k0 + ccol * 8;
+      const bool kok = k < p.Ktot;
+      int tap = 0, c = k;
+      if (!pointwise) { tap = k / Cin; c = k - tap * Cin; }
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const T* s = src1; int cs = p.C1; int cc = c;
+      if (c >= p.C1) { s = src2; cs = p.C2; cc = c - p.C1; }
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        ra[i] = v8_zero<T>();
+        if (a_ok[i] && kok) {
+          if (pointwise) {
+            ra[i] = v8_load<T>(s + (size_t)a_w[i] * cs + cc);
+          } else {
+            int hi = a_h[i] + kh * p.dil, wi = a_w[i] + kw * p.dil;
+            if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+              ra[i] = v8_load<T>(s + ((size_t)(a_b[i] * p.H + hi) * p.W + wi) * cs + cc);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        int q = tid + i * 256;
+        int r = q / CPR;
+        int n = n0 + r;
+        rb[i] = v8_zero<T>();
+        if (q < BN * CPR && n < p.N && kok) rb[i] = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
+      }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        int q = tid + i * 256;
+        if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, ra[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        int q = tid + i * 256;
+        if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, rb[i]);
+      }
+    };
+
+    load_tiles(0);
+    for (int k0 = 0; k0 < p.Ktot; k0 += BK) {
+      __syncthreads();  // previous tile fully consumed
+      store_tiles();
+      __syncthreads();
+      if (k0 + BK < p.Ktot) load_tiles(k0 + BK);  // prefetch next tile into registers under the MFMAs
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        Frag<T> a = lds_frag(As, PITCH, wave_m * 32, kk, lane);
+        static_for<0, NF>([&](auto fi) {
+          constexpr int f = decltype(fi)::value;
+          Frag<T> b = lds_frag(Bs, PITCH, wave_n * (32 * NF) + f * 32, kk, lane);
+          mma32(acc[f], a, b);
+        });
+      }
+    }
+
+    // ---- epilogue ---- (compile-time frag index: keeps acc[] in registers for every NF)
+    static_for<0, NF>([&](auto fi) {
+      constexpr int f = decltype(fi)::value;
+      const int n = n0 + wave_n * (32 * NF) + f * 32 + (lane & 31);
+      const bool nok = n < p.N;
+      const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave_m * 32 + acc_row(r, lane);
+        if (nok && m < p.M) {
+          const size_t o = (size_t)m * p.N + n;
+          float v = acc[f][r] + bias;
+          if (p.save_pre) reinterpret_cast<T*>(p.save_pre)[o] = from_f<T>(v);
+          v = act_fwd(v, p.act);
+          if (p.actgrad_aux) v *= act_grad(to_f<T>(reinterpret_cast<const T*>(p.actgrad_aux)[o]), p.actgrad_act);
+          if (p.drop_p > 0.f) v *= dropout_scale(seed, p.stream_id, o, p.drop_p, inv_keep);
+          if (p.residual) v += to_f<T>(reinterpret_cast<const T*>(p.residual)[o]);
+          T tv = from_f<T>(v);
+          out[o] = tv;
+          float vr = to_f<T>(tv);
+          cs1[f] += vr;
+          cs2[f] += vr * vr;
+        }
+      }
+    });
+  }
+
+  if (p.stats_part) {
+    // combine the two half-waves (same column, different rows), then the WM waves stacked along M
+    static_for<0, NF>([&](auto fi) {
+      constexpr int f = decltype(fi)::value;
+      float s1 = cs1[f] + __shfl_xor(cs1[f], 32, 64);
+      float s2 = cs2[f] + __shfl_xor(cs2[f], 32, 64);
+      if (lane < 32) {
+        int col = wave_n * (32 * NF) + f * 32 + lane;
+        red[(wave_m * 2 + 0) * BN + col] = s1;
+        red[(wave_m * 2 + 1) * BN + col] = s2;
+      }
+    });
+    __syncthreads();
+    for (int col = tid; col < BN; col += 256) {
+      int n = n0 + col;
+      if (n < p.N) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += red[(w * 2 + 0) * BN + col];
+          s2 += red[(w * 2 + 1) * BN + col];
+        }
+        p.stats_part[(size_t)blockIdx.x * 2 * p.N + n] = s1;
+        p.stats_part[(size_t)blockIdx.x * 2 * p.N + p.N + n] = s2;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// dW kernel:  dW[n, k] += sum_{m in split} dY[m, n] * A(m, k)         (both operands M-major in HBM)
+// Tile 128(n) x 128(k) per workgroup, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles.
+// Both operand tiles are transposed on their way into LDS (so fragments are contiguous in m):
+// lanes run along m in row PAIRS and write packed {row 2i, row 2i+1} words.
+// =============================================================================================
+struct GemmTNParams {
+  const void* dy;
+  const void* src1;
+  const void* src2;
+  int C1, C2;
+  float* dw;
+  int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
+  int M, N, Ktot;
+  int Cin_real;
+  int m_per_split;
+  int k_tiles;
+};
+
+__device__ __forceinline__ void store_transposed_pair(bf16_t* dst, int pitch, const V8<bf16_t>& r0, const V8<bf16_t>& r1) {
+  const uint32_t a[4] = {r0.d.x, r0.d.y, r0.d.z, r0.d.w};
+  const uint32_t b[4] = {r1.d.x, r1.d.y, r1.d.z, r1.d.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint32_t w = (j & 1) ? ((a[j >> 1] >> 16) | (b[j >> 1] & 0xffff0000u)) : ((a[j >> 1] & 0xffffu) | (b[j >> 1] << 16));
+    *reinterpret_cast<uint32_t*>(dst + j * pitch) = w;
+  }
+}
+__device__ __forceinline__ void store_transposed_pair(float* dst, int pitch, const V8<float>& r0, const V8<float>& r1) {
+  float a[8], b[8];
+  v8_unpack(r0, a);
+  v8_unpack(r1, b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<float2*>(dst + j * pitch) = make_float2(a[j], b[j]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
+  constexpr int BMR = 32;
+  constexpr int PITCH = lds_pitch<T>(BMR);
+  __shared__ __attribute__((aligned(16))) T Dt[128 * PITCH];
+  __shared__ __attribute__((aligned(16))) T Xt[128 * PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 1, wave_k = wave & 1;
+  const int tile_n = blockIdx.x / p.k_tiles, tile_k = blockIdx.x % p.k_tiles;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int Cin = p.C1 + p.C2;
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const bool pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
+
+  const int mp = tid & 15;   // row pair inside the 32-row stage
+  const int nc = tid >> 4;   // 8-wide column chunk (0..15) of the 128-wide tiles
+  // dY column / A(m,k) column handled by this thread
+  const int n_col = n0 + nc * 8;
+  const bool n_ok = n_col < p.N;
+  const int k_col = k0 + nc * 8;
+  const bool k_ok = k_col < p.Ktot;
+  int tap = 0, c = k_col;
+  if (!pointwise && k_ok) { tap = k_col / Cin; c = k_col - tap * Cin; }
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const T* s = reinterpret_cast<const T*>(p.src1);
+  int cs = p.C1, cc = c;
+  if (c >= p.C1) { s = reinterpret_cast<const T*>(p.src2); cs = p.C2; cc = c - p.C1; }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
+
+  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  V8<T> d0, d1, x0, x1;
+  auto load_stage = [&](int ms) {
+    d0 = d1 = x0 = x1 = v8_zero<T>();
+    const int ma = ms + 2 * mp, mb = ma + 1;
+    if (n_ok) {
+      if (ma < m_end) d0 = v8_load<T>(dy + (size_t)ma * p.N + n_col);
+      if (mb < m_end) d1 = v8_load<T>(dy + (size_t)mb * p.N + n_col);
+    }
+    if (k_ok) {
+      if (pointwise) {
+        if (ma < m_end) x0 = v8_load<T>(s + (size_t)ma * cs + cc);
+        if (mb < m_end) x1 = v8_load<T>(s + (size_t)mb * cs + cc);
+      } else {
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int m = e ? mb : ma;
+          if (m < m_end) {
+            int b = m / hw;
+            int rem = m - b * hw;
+            int ho = rem / p.Wo;
+            int wo = rem - ho * p.Wo;
+            int hi = ho * p.stride - p.pad + kh * p.dil, wi = wo * p.stride - p.pad + kw * p.dil;
+            if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+              V8<T> v = v8_load<T>(s + ((size_t)(b * p.H + hi) * p.W + wi) * cs + cc);
+              if (e) x1 = v; else x0 = v;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  if (m_begin < m_end) load_stage(m_begin);
+  for (int ms = m_begin; ms < m_end; ms += BMR) {
+    __syncthreads();
+    store_transposed_pair(Dt + (nc * 8) * PITCH + 2 * mp, PITCH, d0, d1);
+    store_transposed_pair(Xt + (nc * 8) * PITCH + 2 * mp, PITCH, x0, x1);
+    __syncthreads();
+    if (ms + BMR < m_end) load_stage(ms + BMR);
+#pragma unroll
+    for (int kk = 0; kk < BMR; kk += 16) {
+      Frag<T> a0 = lds_frag(Dt, PITCH, wave_n * 64, kk, lane);
+      Frag<T> a1 = lds_frag(Dt, PITCH, wave_n * 64 + 32, kk, lane);
+      Frag<T> b0 = lds_frag(Xt, PITCH, wave_k * 64, kk, lane);
+      Frag<T> b1 = lds_frag(Xt, PITCH, wave_k * 64 + 32, kk, lane);
+      mma32(acc[0][0], a0, b0);
+      mma32(acc[0][1], a0, b1);
+      mma32(acc[1][0], a1, b0);
+      mma32(acc[1][1], a1, b1);
+    }
+  }
+
+  const int khw = p.KH * p.KW;
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+    for (int fk = 0; fk < 2; ++fk) {
+      const int k = k0 + wave_k * 64 + fk * 32 + (lane & 31);
+      if (k >= p.Ktot) continue;
+      int t2 = 0, c2 = k;
+      if (!pointwise) { t2 = k / Cin; c2 = k - t2 * Cin; }
+      if (c2 >= p.Cin_real) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
+        if (n < p.N) atomicAdd(p.dw + ((size_t)n * p.Cin_real + c2) * khw + t2, acc[fn][fk][r]);
+      }
+    }
+}
+
+// =============================================================================================
+// host-side dispatch
+// =============================================================================================
+template <typename T, int WM, int WN, int NF, int BK>
+static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
+  constexpr int BM = 32 * WM, BN = 32 * NF * WN;
+  ConvGemmParams p = p0;
+  p.m_tiles = (p.M + BM - 1) / BM;
+  const int n_tiles = (p.N + BN - 1) / BN;
+  int gx = p.m_tiles < 2048 ? p.m_tiles : 2048;
+  dim3 grid(gx, n_tiles);
+  size_t smem = (size_t)(BM + BN) * lds_pitch<T>(BK) * sizeof(T) + (size_t)WM * 2 * BN * sizeof(float);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, WM, WN, NF, BK>), grid, dim3(256), smem, st, p);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int BK>
+static int dispatch_conv_gemm_nf(const ConvGemmParams& p, int nf, bool small_m, hipStream_t st) {
+  if (small_m && nf >= 4) return launch_conv_gemm<T, 2, 2, 4, BK>(p, st);  // BM = 64, BN = 256
+  switch (nf) {
+    case 1: return launch_conv_gemm<T, 4, 1, 1, BK>(p, st);
+    case 2: return launch_conv_gemm<T, 4, 1, 2, BK>(p, st);
+    case 3: return launch_conv_gemm<T, 4, 1, 3, BK>(p, st);
+    case 4: return launch_conv_gemm<T, 4, 1, 4, BK>(p, st);
+    case 5: return launch_conv_gemm<T, 4, 1, 5, BK>(p, st);
+    case 6: return launch_conv_gemm<T, 4, 1, 6, BK>(p, st);
+    default: return launch_conv_gemm<T, 4, 1, 8, BK>(p, st);
+  }
+}
+
+// choose the N tiling: fewest padded columns, then fewest tiles
+static int choose_nf(int N) {
+  static const int cand[7] = {1, 2, 3, 4, 5, 6, 8};
+  int best = 8, best_cost = 1 << 30;
+  for (int i = 0; i < 7; ++i) {
+    int bn = 32 * cand[i];
+    int tiles = (N + bn - 1) / bn;
+    int cost = tiles * bn * 16 + tiles;  // padded width dominates, tile count breaks ties
+    if (cost < best_cost) { best_cost = cost; best = cand[i]; }
+  }
+  return best;
+}
+
+extern "C" int cvh_conv_gemm_grid_rows(int M, int N) {
+  // number of stats-partial rows conv_gemm writes for an (M, N) problem (== gridDim.x)
+  int nf = choose_nf(N);
+  bool small_m = (M <= 16384) && nf >= 4;
+  int bm = small_m ? 64 : 128;
+  int mt = (M + bm - 1) / bm;
+  return mt < 2048 ? mt : 2048;
+}
+
+extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2, const void* wgt, void* out,
+                             int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                             const float* bias, int act, void* save_pre, const void* actgrad_aux, int actgrad_act,
+                             const void* residual, float drop_p, const unsigned long long* seed, unsigned int stream_id,
+                             float* stats_part, void* stream) {
+  if ((C1 % 8) != 0 || (C2 % 8) != 0 || C1 <= 0) return -2;
+  if (src2 == nullptr && C2 != 0) return -2;
+  ConvGemmParams p;
+  p.src1 = src1; p.src2 = src2; p.C1 = C1; p.C2 = C2; p.wgt = wgt; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.M = B * Ho * Wo; p.N = N; p.Ktot = KH * KW * (C1 + C2);
+  p.bias = bias; p.act = act; p.save_pre = save_pre; p.actgrad_aux = actgrad_aux; p.actgrad_act = actgrad_act;
+  p.residual = residual; p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id; p.stats_part = stats_part;
+  p.m_tiles = 0;
+  if (p.M <= 0 || N <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nf = choose_nf(N);
+  const bool small_m = (p.M <= 16384) && nf >= 4;
+  const bool bk64 = p.Ktot >= 64;
+  if (dtype == CVH_DT_BF16) {
+    return bk64 ? dispatch_conv_gemm_nf<bf16_t, 64>(p, nf, small_m, st) : dispatch_conv_gemm_nf<bf16_t, 32>(p, nf, small_m, st);
+  } else if (dtype == CVH_DT_F32) {
+    return dispatch_conv_gemm_nf<float, 32>(p, nf, small_m, st);
+  }
+  return -1;
+}
+
+extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw,
+                           int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                           int Cin_real, void* stream) {
+  if ((C1 % 8) != 0 || (C2 % 8) != 0 || (N % 8) != 0) return -2;
+  GemmTNParams p;
+  p.dy = dy; p.src1 = src1; p.src2 = src2; p.C1 = C1; p.C2 = C2; p.dw = dw;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.M = B * Ho * Wo; p.N = N; p.Ktot = KH * KW * (C1 + C2); p.Cin_real = Cin_real;
+  if (p.M <= 0) return 0;
+  const int n_tiles = (N + 127) / 128;
+  p.k_tiles = (p.Ktot + 127) / 128;
+  const int out_tiles = n_tiles * p.k_tiles;
+  // enough splits over M to fill the chip (~1024 workgroups), each at least 256 rows
+  int splits = (1024 + out_tiles - 1) / out_tiles;
+  int max_splits = (p.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int mps = (p.M + splits - 1) / splits;
+  mps = ((mps + 31) / 32) * 32;
+  splits = (p.M + mps - 1) / mps;
+  p.m_per_split = mps;
+  dim3 grid(out_tiles, splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, p);
+  else return -1;
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

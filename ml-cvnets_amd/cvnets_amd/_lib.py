@@ -1,0 +1,98 @@
+"""ctypes binding of libcvnets_hip.so (C ABI declared in include/cvnets_hip.h).
+
+There is NO CPU fallback: if the library is missing every op raises.  The .so is built in-tree by
+``ml-cvnets_amd/build.py`` (``__graft_entry__.build()``), never pip-installed.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_longlong, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvnets_hip.so")
+
+P = c_void_p
+I = c_int
+F = c_float
+L = c_longlong
+U = c_uint
+D = c_double
+
+# name -> argtypes ; mirrors include/cvnets_hip.h one-to-one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "cvh_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
+    "cvh_nhwc_to_nchw": [I, P, P, I, I, I, I, I, P],
+    "cvh_weight_pack": [I, P, P, I, I, I, I, P],
+    "cvh_cast_from_f32": [I, P, P, L, P],
+    "cvh_cast_to_f32": [I, P, P, L, P],
+    "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
+    "cvh_conv_gemm_grid_rows": [I, I],
+    "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cvh_dwconv_fwd": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
+    "cvh_dwconv_rows": [I, I, I, I],
+    "cvh_dwconv_bwd_x": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cvh_dwconv_bwd_w": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cvh_dwconv_bwd_w_rows": [I, I, I, I],
+    "cvh_colreduce_rows": [L, I],
+    "cvh_bn_stats": [I, P, L, I, P, P],
+    "cvh_bn_finalize": [P, I, I, D, P, P, P, P, F, F, P, P, P, P, P],
+    "cvh_bn_eval_coeff": [P, P, P, P, F, I, P, P, P, P, P],
+    "cvh_bn_apply": [I, P, P, P, I, P, P, L, I, P],
+    "cvh_bn_bwd_reduce": [I, P, P, P, P, P, P, I, L, I, P, P],
+    "cvh_bn_bwd_finalize": [P, I, I, D, P, P, P, I, P, P, P, P, P, P],
+    "cvh_bn_bwd_apply": [I, P, P, P, P, I, P, P, P, P, L, I, P],
+    "cvh_colsum": [I, P, L, I, P, P, F, P],
+    "cvh_sum_partials": [P, I, I, P, F, P],
+    "cvh_pool_fwd": [I, P, P, I, I, I, P],
+    "cvh_pool_bwd": [I, P, P, I, I, I, P],
+    "cvh_dropout": [I, P, P, L, F, P, U, P],
+    "cvh_seed_advance": [P, P],
+    "cvh_add": [I, P, P, P, L, P],
+    "cvh_layernorm_fwd": [I, P, P, P, P, P, P, L, I, F, P],
+    "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
+    "cvh_ln_bwd_rows": [L],
+    "cvh_attn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
+    "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises HipLibraryMissing if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python ml-cvnets_amd/build.py` (hipcc, gfx950). "
+            "cvnets_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> int:
+    """Invoke a status-returning entry point; raise RuntimeError on any non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}" + (" (HIP out of memory)" if rc == 2 else ""))
+    return rc
+
+
+def query(name: str, *args) -> int:
+    """Invoke a size-query entry point (returns a count, negative = rejected arguments)."""
+    rc = getattr(load(), name)(*args)
+    if rc < 0:
+        raise RuntimeError(f"{name}{args} rejected its arguments (status {rc})")
+    return rc

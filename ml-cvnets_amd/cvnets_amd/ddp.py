@@ -1,0 +1,162 @@
+"""Data-parallel gradient exchange for the hot path: one process per GPU, RCCL (torch.distributed backend "nccl" on
+ROCm) over xGMI.  Replaces torch.nn.parallel.DistributedDataParallel at main_train.py:90-96 and the rendezvous of
+utils/ddp_utils.py:47-89 (same contract: ``.module``, parameters/buffers broadcast from rank 0, gradients averaged).
+
+Design for the 8-GPU xGMI mesh (7 links x ~153 GB/s per GPU, point-to-point):
+  * every parameter gradient lives in a FLAT fp32 bucket (``p.grad`` is a view), so a bucket is one contiguous RCCL
+    message — few, large collectives (MobileViT-S: 22.3 MB = 1 bucket at the default 25 MB cap; ViT-B: 14 buckets);
+  * buckets are filled in reverse-registration order (≈ autograd order); when the last gradient of a bucket has been
+    accumulated its all-reduce is enqueued on a SIDE HIP stream behind an event, overlapping the rest of backward;
+  * ``finish`` (queued as an autograd end-of-backward callback) makes the compute stream wait for the side stream and
+    applies the 1/world_size average;
+  * with hipGraph-captured steps (bench.py) hooks do not fire on replay, so ``allreduce_flat`` runs the same buckets
+    right after the replay on the side stream.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+def distributed_init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> int:
+    """utils/ddp_utils.py:47-89: env:// rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher),
+    then one dummy all-reduce to create the communicator (ddp_utils.py:84-85).  Returns the rank."""
+    if dist.is_initialized():
+        return dist.get_rank()
+    if backend is None:
+        backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "30786")
+    kwargs = {}
+    if backend == "nccl" and device is not None:
+        kwargs["device_id"] = device
+    dist.init_process_group(backend=backend, init_method="env://", **kwargs)
+    t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    return dist.get_rank()
+
+
+class _Bucket:
+    def __init__(self, params: List[nn.Parameter], device):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        off = 0
+        for p in params:
+            p.grad = self.flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class DistributedDataParallel(nn.Module):
+    def __init__(self, module: nn.Module, bucket_cap_mb: float = 25.0, overlap: bool = True, broadcast_buffers: bool = True,
+                 process_group=None):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self.broadcast_buffers = broadcast_buffers
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.device = params[0].device
+        self.use_side_stream = self.device.type == "cuda"
+        self.side_stream = torch.cuda.Stream(device=self.device) if self.use_side_stream else None
+        # parameters + buffers start identical on every rank (DDP ctor broadcast)
+        if self.world > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=self.pg)
+        # buckets in reverse registration order: the last layers' gradients are ready first
+        cap = int(bucket_cap_mb * 1024 * 1024 / 4)
+        self.buckets: List[_Bucket] = []
+        cur, cur_n = [], 0
+        for p in reversed(params):
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(_Bucket(cur, self.device))
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(_Bucket(cur, self.device))
+        self._bucket_of = {}
+        for b in self.buckets:
+            for p in b.params:
+                self._bucket_of[p] = b
+                p.register_post_accumulate_grad_hook(self._hook)
+        self._callback_queued = False
+        self.hooks_enabled = True
+
+    # ---- autograd-driven path (eager) --------------------------------------------------------
+    def _hook(self, p: nn.Parameter):
+        if not self.hooks_enabled or self.world == 1:
+            return
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        b = self._bucket_of[p]
+        b.pending -= 1
+        if b.pending == 0 and self.overlap:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        if self.use_side_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side_stream.wait_event(ev)
+            with torch.cuda.stream(self.side_stream):
+                b.work = dist.all_reduce(b.flat, group=self.pg, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, group=self.pg, async_op=True)
+
+    def finish(self):
+        """end of backward: launch whatever was not launched, wait, average."""
+        for b in self.buckets:
+            if b.work is None:
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            b.work = None
+            b.pending = len(b.params)
+        if self.use_side_stream:
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+        for b in self.buckets:
+            b.flat.div_(self.world)
+        self._callback_queued = False
+
+    # ---- explicit path (after a hipGraph replay) ---------------------------------------------
+    def allreduce_flat(self):
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            b.work = None
+        if self.use_side_stream:
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+        for b in self.buckets:
+            b.flat.div_(self.world)
+
+    def zero_grad(self, set_to_none: bool = False):
+        """gradients are views of the flat buckets: zero in place (never set to None)."""
+        for b in self.buckets:
+            b.flat.zero_()
+
+    def grad_bytes(self) -> int:
+        return sum(b.numel for b in self.buckets) * 4
+
+    def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.world > 1 and self.training:
+            bufs = [b for b in self.module.buffers() if b.dtype.is_floating_point]
+            if bufs:
+                flat = torch.cat([b.reshape(-1) for b in bufs])
+                dist.broadcast(flat, src=0, group=self.pg)
+                off = 0
+                for b in bufs:
+                    b.copy_(flat[off: off + b.numel()].view_as(b))
+                    off += b.numel()
+        return self.module(*args, **kwargs)

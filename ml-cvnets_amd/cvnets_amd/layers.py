@@ -1,0 +1,380 @@
+"""Host-side mirror of ``cvnets.layers`` for the hot path: same class names, constructor signatures,
+attribute / sub-module tree and ``state_dict`` keys as the reference, with ``forward`` routed to the HIP
+kernels (``cvnets_amd.ops``).  Reference file:line is cited per class.
+
+Because the attribute trees are identical, a model built by the *reference* (``cvnets.get_model``) can be
+switched to this implementation by class-swapping its modules in place (see ``cvnets_amd.dropin``).
+"""
+from __future__ import annotations
+
+import argparse
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+# ---------------------------------------------------------------------------------------------
+# opts helpers: the reference reads dotted names off an argparse.Namespace with getattr
+# ---------------------------------------------------------------------------------------------
+
+
+def opt(opts, name: str, default=None):
+    return getattr(opts, name, default) if opts is not None else default
+
+
+def default_opts(**overrides) -> argparse.Namespace:
+    """Namespace pre-filled with the model-side values of config/classification/imagenet/mobilevit.yaml."""
+    ns = argparse.Namespace()
+    base = {
+        "model.classification.name": "mobilevit",
+        "model.classification.n_classes": 1000,
+        "model.classification.classifier_dropout": 0.1,
+        "model.classification.mit.mode": "small",
+        "model.classification.mit.ffn_dropout": 0.0,
+        "model.classification.mit.attn_dropout": 0.0,
+        "model.classification.mit.dropout": 0.1,
+        "model.classification.mit.number_heads": 4,
+        "model.classification.mit.head_dim": None,
+        "model.classification.mit.no_fuse_local_global_features": False,
+        "model.classification.mit.conv_kernel_size": 3,
+        "model.classification.mit.transformer_norm_layer": "layer_norm",
+        "model.normalization.name": "batch_norm",
+        "model.normalization.momentum": 0.1,
+        "model.activation.name": "swish",
+        "model.activation.inplace": False,
+        "model.activation.neg_slope": 0.1,
+        "model.layer.global_pool": "mean",
+    }
+    base.update(overrides)
+    for k, v in base.items():
+        setattr(ns, k, v)
+    return ns
+
+
+# ---------------------------------------------------------------------------------------------
+# activations  (cvnets/layers/activation/{swish,gelu}.py; registry cvnets/layers/activation/__init__.py:15-102)
+# ---------------------------------------------------------------------------------------------
+class Swish(nn.SiLU):
+    def __init__(self, inplace: Optional[bool] = False, *args, **kwargs) -> None:
+        super().__init__(inplace=inplace)
+
+
+class GELU(nn.GELU):
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__()
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+ACT_FN_REGISTRY = {"swish": Swish, "gelu": GELU}
+
+
+def build_activation_layer(opts=None, act_type: Optional[str] = None, inplace: Optional[bool] = None, *args, **kwargs) -> nn.Module:
+    if act_type is None:
+        act_type = opt(opts, "model.activation.name", "swish")
+    act_type = act_type.lower()
+    if act_type not in ACT_FN_REGISTRY:
+        raise NotImplementedError(f"activation '{act_type}' is not on the HIP hot path (supported: {sorted(ACT_FN_REGISTRY)})")
+    return ACT_FN_REGISTRY[act_type](inplace=bool(inplace))
+
+
+def act_code(m: Optional[nn.Module]) -> int:
+    if m is None or isinstance(m, (Identity, nn.Identity)):
+        return ops.ACT_NONE
+    if isinstance(m, nn.SiLU):
+        return ops.ACT_SILU
+    if isinstance(m, nn.GELU):
+        return ops.ACT_GELU
+    raise NotImplementedError(f"activation {m.__class__.__name__} has no HIP kernel")
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation  (cvnets/layers/normalization/{batch_norm,layer_norm}.py; registry normalization/__init__.py:16-88)
+# ---------------------------------------------------------------------------------------------
+class BatchNorm2d(nn.BatchNorm2d):
+    def __init__(self, num_features: int, eps: Optional[float] = 1e-5, momentum: Optional[float] = 0.1, affine: Optional[bool] = True,
+                 track_running_stats: Optional[bool] = True, *args, **kwargs) -> None:
+        super().__init__(num_features=num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = ops.to_nhwc(x)
+        training = self.training or not self.track_running_stats
+        if self.training and self.track_running_stats:
+            self.num_batches_tracked.add_(1)  # plumbing (scalar counter)
+        return ops.BatchNormAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                      (ops.ACT_NONE, training, float(self.momentum), float(self.eps)))
+
+
+class LayerNorm(nn.LayerNorm):
+    """cvnets/layers/normalization/layer_norm.py:14-72.  The channel-last branch (:67-68) is the HIP kernel.  The
+    reference's channel-first branch (:53-66, taken whenever x.shape[1] == C and ndim > 2 — also, by accident, for a
+    [B', S, C] token tensor with S == C) is NOT reproduced: it is rejected loudly (see DESIGN.md "LayerNorm quirk")."""
+
+    def __init__(self, normalized_shape, eps: Optional[float] = 1e-5, elementwise_affine: Optional[bool] = True, *args, **kwargs):
+        super().__init__(normalized_shape=normalized_shape, eps=eps, elementwise_affine=elementwise_affine)
+
+    def forward(self, x: Tensor) -> Tensor:
+        c = self.normalized_shape[0]
+        if x.ndim > 2 and x.shape[1] == c and x.shape[-1] != c:
+            raise NotImplementedError("channel-first LayerNorm is not on the HIP hot path")
+        if x.shape[-1] != c:
+            raise NotImplementedError("LayerNorm is supported for channel-last format only")
+        shp = x.shape
+        y = ops.layer_norm(x.reshape(-1, c), self.weight, self.bias, self.eps)
+        return y.view(shp)
+
+
+NORM_LAYER_REGISTRY = {"batch_norm": BatchNorm2d, "batch_norm_2d": BatchNorm2d, "layer_norm": LayerNorm}
+
+
+def get_normalization_layer(opts, num_features: int, norm_type: Optional[str] = None, num_groups: Optional[int] = None, *args, **kwargs):
+    """cvnets/layers/normalization/__init__.py:35-88 (build_normalization_layer)."""
+    if norm_type is None:
+        norm_type = opt(opts, "model.normalization.name", "batch_norm")
+    momentum = opt(opts, "model.normalization.momentum", 0.1)
+    norm_type = norm_type.lower()
+    if norm_type not in NORM_LAYER_REGISTRY:
+        raise NotImplementedError(f"normalisation '{norm_type}' is not on the HIP hot path (supported: {sorted(NORM_LAYER_REGISTRY)})")
+    return NORM_LAYER_REGISTRY[norm_type](normalized_shape=num_features, num_features=num_features, momentum=momentum)
+
+
+# ---------------------------------------------------------------------------------------------
+# conv  (cvnets/layers/conv_layer.py:18-66 Conv2d, :69-277 ConvLayer2d)
+# ---------------------------------------------------------------------------------------------
+class Conv2d(nn.Conv2d):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, dilation=1, groups: int = 1, bias: bool = False,
+                 padding_mode: str = "zeros", *args, **kwargs) -> None:
+        super().__init__(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                         dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _conv_forward(self, None, None, x, self.training)
+
+
+def _conv_geometry(conv: nn.Conv2d) -> Tuple[int, int, int]:
+    if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation[0] != conv.dilation[1] \
+            or conv.kernel_size[0] != conv.kernel_size[1]:
+        raise NotImplementedError("anisotropic conv geometry is not on the HIP hot path")
+    if conv.padding_mode != "zeros":
+        raise NotImplementedError("only zero padding is on the HIP hot path")
+    return conv.stride[0], conv.padding[0], conv.dilation[0]
+
+
+def _conv_forward(conv: nn.Conv2d, norm: Optional[nn.Module], act: Optional[nn.Module], x: Tensor, training: bool,
+                  residual: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
+    x = ops.to_nhwc(x)
+    stride, pad, dil = _conv_geometry(conv)
+    a = act_code(act)
+    use_bn = norm is not None
+    g = be = rm = rv = None
+    momentum, eps, bn_training = 0.1, 1e-5, training
+    if use_bn:
+        if not isinstance(norm, nn.BatchNorm2d):
+            raise NotImplementedError(f"{norm.__class__.__name__} after a conv is not on the HIP hot path")
+        g, be, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
+        momentum, eps = norm.momentum, norm.eps
+        bn_training = norm.training or not norm.track_running_stats
+        if norm.training and norm.track_running_stats:
+            norm.num_batches_tracked.add_(1)  # plumbing (scalar counter)
+    if conv.groups == 1:
+        return ops.conv_bn_act(x, conv.weight, conv.bias, g, be, rm, rv, stride=stride, pad=pad, dil=dil, act=a, use_bn=use_bn,
+                               training=bn_training, momentum=momentum, eps=eps, residual=residual, x2=x2)
+    if conv.groups == conv.in_channels == conv.out_channels and conv.bias is None and residual is None and x2 is None:
+        return ops.dwconv_bn_act(x, conv.weight, g, be, rm, rv, stride=stride, pad=pad, dil=dil, act=a, use_bn=use_bn,
+                                 training=bn_training, momentum=momentum, eps=eps)
+    raise NotImplementedError("grouped convs other than depthwise are not on the HIP hot path")
+
+
+class ConvLayer2d(nn.Module):
+    """conv -> norm? -> act? as ``self.block`` (children ``conv``, ``norm``, ``act``); cvnets/layers/conv_layer.py:117-277."""
+
+    def __init__(self, opts, in_channels: int, out_channels: int, kernel_size: Union[int, Tuple[int, int]], stride=1, dilation=1,
+                 padding=None, groups: int = 1, bias: bool = False, padding_mode: str = "zeros", use_norm: bool = True, use_act: bool = True,
+                 norm_layer: Optional[nn.Module] = None, act_layer: Optional[nn.Module] = None, *args, **kwargs) -> None:
+        super().__init__()
+        if norm_layer is None and use_norm:
+            norm_type = opt(opts, "model.normalization.name", "batch_norm")
+            if norm_type == "batch_norm":
+                norm_type = "batch_norm_2d"
+            norm_layer = get_normalization_layer(opts=opts, num_features=out_channels, norm_type=norm_type)
+        if act_layer is None and use_act:
+            act_layer = build_activation_layer(opts)
+        if use_norm and bias and any(n == "bias" for n, _ in norm_layer.named_parameters()):
+            raise AssertionError("Do not use bias when using normalization layers with bias.")
+        if use_norm and isinstance(norm_layer, LayerNorm):
+            bias = True
+        if isinstance(kernel_size, int):
+            kernel_size = (kernel_size, kernel_size)
+        if isinstance(stride, int):
+            stride = (stride, stride)
+        if isinstance(dilation, int):
+            dilation = (dilation, dilation)
+        if padding is None:
+            padding = tuple(int((kernel_size[i] - 1) / 2) * dilation[i] for i in range(2))
+        if in_channels % groups or out_channels % groups:
+            raise ValueError("channels are not divisible by groups")
+        block = nn.Sequential()
+        conv = Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                      dilation=dilation, groups=groups, bias=bias, padding_mode=padding_mode)
+        block.add_module(name="conv", module=conv)
+        self.norm_name = None
+        if use_norm:
+            block.add_module(name="norm", module=norm_layer)
+            self.norm_name = norm_layer.__class__.__name__
+        self.act_name = None
+        if use_act:
+            block.add_module(name="act", module=act_layer)
+            self.act_name = act_layer.__class__.__name__
+        self.block = block
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.stride = stride
+        self.groups = groups
+        self.kernel_size = conv.kernel_size
+        self.bias = bias
+        self.dilation = dilation
+
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
+        blk = self.block
+        norm = getattr(blk, "norm", None) if "norm" in blk._modules else None
+        act = getattr(blk, "act", None) if "act" in blk._modules else None
+        return _conv_forward(blk.conv, norm, act, x, self.training, residual=residual, x2=x2)
+
+    def __repr__(self):
+        s = self.block[0].__repr__()[:-1]
+        if self.norm_name is not None:
+            s += ", normalization={}".format(self.norm_name)
+        if self.act_name is not None:
+            s += ", activation={}".format(self.act_name)
+        return s + ")"
+
+
+# ---------------------------------------------------------------------------------------------
+# linear / dropout / pooling  (cvnets/layers/linear_layer.py:17-103, dropout.py:11-29, global_pool.py:16-83)
+# ---------------------------------------------------------------------------------------------
+class LinearLayer(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: Optional[bool] = True, channel_first: Optional[bool] = False, *args, **kwargs):
+        super().__init__()
+        self.weight = nn.Parameter(torch.Tensor(out_features, in_features))
+        self.bias = nn.Parameter(torch.Tensor(out_features)) if bias else None
+        self.in_features = in_features
+        self.out_features = out_features
+        self.channel_first = channel_first
+        self.reset_params()
+
+    def reset_params(self) -> None:  # linear_layer.py:68-72
+        if self.weight is not None:
+            torch.nn.init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            torch.nn.init.constant_(self.bias, 0)
+
+    def forward(self, x: Tensor, act: int = ops.ACT_NONE, drop_p: float = 0.0, residual: Optional[Tensor] = None) -> Tensor:
+        if self.channel_first:
+            raise NotImplementedError("channel_first LinearLayer is not on the HIP hot path")
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if x2.dtype != ops.compute_dtype():
+            x2 = x2.to(ops.compute_dtype())  # plumbing: only at a dtype boundary
+        res2 = residual.reshape(-1, self.out_features) if residual is not None else None
+        y = ops.linear(x2.contiguous(), self.weight, self.bias, act=act, drop_p=drop_p, residual=res2)
+        return y.view(*shp[:-1], self.out_features)
+
+    def __repr__(self):
+        return "{}(in_features={}, out_features={}, bias={}, channel_first={})".format(
+            self.__class__.__name__, self.in_features, self.out_features, self.bias is not None, self.channel_first)
+
+
+class Dropout(nn.Dropout):
+    def __init__(self, p: Optional[float] = 0.5, inplace: Optional[bool] = False, *args, **kwargs) -> None:
+        super().__init__(p=p, inplace=inplace)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.dropout(x, self.p, self.training)
+
+
+class GlobalPool(nn.Module):
+    pool_types = ["mean", "rms", "abs"]
+
+    def __init__(self, pool_type: Optional[str] = "mean", keep_dim: Optional[bool] = False, *args, **kwargs) -> None:
+        super().__init__()
+        if pool_type != "mean":
+            raise NotImplementedError("only mean pooling is on the HIP hot path")
+        self.pool_type = pool_type
+        self.keep_dim = keep_dim
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.dim() != 4:
+            raise NotImplementedError("Currently 2D global pooling supported")
+        y = ops.GlobalAvgPool.apply(ops.to_nhwc(x))
+        return y.view(y.shape[0], y.shape[1], 1, 1) if self.keep_dim else y
+
+    def __repr__(self):
+        return "{}(type={})".format(self.__class__.__name__, self.pool_type)
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-head attention  (cvnets/layers/multi_head_attention.py:18-309)
+# ---------------------------------------------------------------------------------------------
+class MultiHeadAttention(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int, attn_dropout: Optional[float] = 0.0, bias: Optional[bool] = True,
+                 output_dim: Optional[int] = None, coreml_compatible: Optional[bool] = False, *args, **kwargs) -> None:
+        if output_dim is None:
+            output_dim = embed_dim
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError(f"Embedding dim must be divisible by number of heads. Got: embed_dim={embed_dim} and num_heads={num_heads}")
+        self.qkv_proj = LinearLayer(in_features=embed_dim, out_features=3 * embed_dim, bias=bias)
+        self.attn_dropout = Dropout(p=attn_dropout)
+        self.out_proj = LinearLayer(in_features=embed_dim, out_features=output_dim, bias=bias)
+        self.head_dim = embed_dim // num_heads
+        self.scaling = self.head_dim ** -0.5
+        self.softmax = nn.Softmax(dim=-1)
+        self.num_heads = num_heads
+        self.embed_dim = embed_dim
+        self.coreml_compatible = coreml_compatible
+        self.use_separate_proj_weight = embed_dim != output_dim
+
+    def __repr__(self):
+        return "{}(head_dim={}, num_heads={}, attn_dropout={})".format(self.__class__.__name__, self.head_dim, self.num_heads, self.attn_dropout.p)
+
+    def forward_tokens(self, x2d: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None, out_drop_p: float = 0.0,
+                       residual: Optional[Tensor] = None) -> Tensor:
+        """qkv projection -> fused attention -> output projection (+dropout +residual in its epilogue)."""
+        if self.attn_dropout.p > 0.0 and self.training:
+            raise NotImplementedError("attention-probability dropout is not implemented in the fused kernel (reference YAMLs use 0.0)")
+        qkv = ops.linear(x2d, self.qkv_proj.weight, self.qkv_proj.bias)
+        o = ops.attention(qkv, self.num_heads, seqmap, causal=causal, key_padding_mask=key_padding_mask)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias, drop_p=out_drop_p, residual=residual)
+
+    def forward(self, x_q: Tensor, x_kv: Optional[Tensor] = None, key_padding_mask: Optional[Tensor] = None,
+                attn_mask: Optional[Tensor] = None, *args, **kwargs) -> Tensor:
+        if x_kv is not None:
+            raise NotImplementedError("cross-attention is not on the HIP hot path")
+        if kwargs.get("use_pytorch_mha", False) or self.coreml_compatible:
+            raise NotImplementedError("forward_pytorch / forward_tracing variants are not on the HIP hot path")
+        b, s, c = x_q.shape
+        causal = False
+        if attn_mask is not None:
+            causal = _mask_is_causal(attn_mask, b, s)
+        x2 = x_q.reshape(b * s, c)
+        if x2.dtype != ops.compute_dtype():
+            x2 = x2.to(ops.compute_dtype())
+        y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask)
+        return y.view(b, s, -1)
+
+
+def _mask_is_causal(attn_mask: Tensor, b: int, s: int) -> bool:
+    """The only additive mask on the reference's path is the CLIP text tower's causal mask
+    (cvnets/text_encoders/transformer.py:343-352); it is generated in-kernel.  Anything else is rejected."""
+    if list(attn_mask.shape) != [b, s, s]:
+        raise AssertionError(f"Shape of attention mask should be [{b}, {s}, {s}]. Got: {attn_mask.shape}")
+    m = attn_mask[0]
+    ref = torch.full((s, s), float("-inf"), device=m.device, dtype=m.dtype).triu(1)
+    if not torch.equal(m, ref):
+        raise NotImplementedError("only the causal additive attention mask is on the HIP hot path")
+    return True

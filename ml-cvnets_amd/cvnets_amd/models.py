@@ -1,0 +1,137 @@
+"""MobileViT backbone + classifier assembled from the HIP-backed layers, with the reference's module tree and
+state_dict keys (cvnets/models/classification/mobilevit.py:19-300, config/mobilevit.py:11-208,
+base_image_encoder.py:261-301).  ``forward`` takes the reference's input ([B,3,H,W] float32 NCHW) and returns
+logits [B, n_classes] in the compute dtype."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .layers import ConvLayer2d, Dropout, GlobalPool, LinearLayer, opt
+from .modules import InvertedResidual, MobileViTBlock
+
+
+def get_configuration(opts) -> Dict:
+    """cvnets/models/classification/config/mobilevit.py:11-208."""
+    mode = opt(opts, "model.classification.mit.mode", "small")
+    head_dim = opt(opts, "model.classification.mit.head_dim", None)
+    num_heads = opt(opts, "model.classification.mit.number_heads", 4)
+    if head_dim is not None and num_heads is not None:
+        raise ValueError("--model.classification.mit.head-dim and --model.classification.mit.number-heads are mutually exclusive.")
+    mode = mode.lower()
+    table = {
+        "xx_small": (2, (16, 24, 48, 64, 80), (64, 80, 96)),
+        "x_small": (4, (32, 48, 64, 80, 96), (96, 120, 144)),
+        "small": (4, (32, 64, 96, 128, 160), (144, 192, 240)),
+    }
+    if mode not in table:
+        raise NotImplementedError(mode)
+    exp, ch, td = table[mode]
+    cfg = {
+        "layer1": {"out_channels": ch[0], "expand_ratio": exp, "num_blocks": 1, "stride": 1, "block_type": "mv2"},
+        "layer2": {"out_channels": ch[1], "expand_ratio": exp, "num_blocks": 3, "stride": 2, "block_type": "mv2"},
+        "last_layer_exp_factor": 4,
+    }
+    for i, (name, nblk) in enumerate((("layer3", 2), ("layer4", 4), ("layer5", 3))):
+        cfg[name] = {"out_channels": ch[2 + i], "transformer_channels": td[i], "ffn_dim": 2 * td[i], "transformer_blocks": nblk,
+                     "patch_h": 2, "patch_w": 2, "stride": 2, "mv_expand_ratio": exp, "head_dim": head_dim, "num_heads": num_heads,
+                     "block_type": "mobilevit"}
+    return cfg
+
+
+class MobileViT(nn.Module):
+    def __init__(self, opts, *args, **kwargs) -> None:
+        super().__init__()
+        num_classes = opt(opts, "model.classification.n_classes", 1000)
+        classifier_dropout = opt(opts, "model.classification.classifier_dropout", 0.0)
+        pool_type = opt(opts, "model.layer.global_pool", "mean")
+        cfg = get_configuration(opts)
+        self.dilation = 1
+        self.model_conf_dict = dict()
+        self.conv_1 = ConvLayer2d(opts=opts, in_channels=3, out_channels=16, kernel_size=3, stride=2, use_norm=True, use_act=True)
+        self.model_conf_dict["conv1"] = {"in": 3, "out": 16}
+        in_channels = 16
+        for idx in range(1, 6):
+            layer, out_channels = self._make_layer(opts=opts, input_channel=in_channels, cfg=cfg[f"layer{idx}"])
+            setattr(self, f"layer_{idx}", layer)
+            self.model_conf_dict[f"layer{idx}"] = {"in": in_channels, "out": out_channels}
+            in_channels = out_channels
+        exp_channels = min(cfg["last_layer_exp_factor"] * in_channels, 960)
+        self.conv_1x1_exp = ConvLayer2d(opts=opts, in_channels=in_channels, out_channels=exp_channels, kernel_size=1, stride=1,
+                                        use_act=True, use_norm=True)
+        self.model_conf_dict["exp_before_cls"] = {"in": in_channels, "out": exp_channels}
+        self.classifier = nn.Sequential()
+        self.classifier.add_module(name="global_pool", module=GlobalPool(pool_type=pool_type, keep_dim=False))
+        if 0.0 < classifier_dropout < 1.0:
+            self.classifier.add_module(name="dropout", module=Dropout(p=classifier_dropout, inplace=True))
+        self.classifier.add_module(name="fc", module=LinearLayer(in_features=exp_channels, out_features=num_classes, bias=True))
+        self.n_classes = num_classes
+
+    def _make_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+        if cfg.get("block_type", "mobilevit").lower() == "mobilevit":
+            return self._make_mit_layer(opts, input_channel, cfg)
+        return self._make_mobilenet_layer(opts, input_channel, cfg)
+
+    @staticmethod
+    def _make_mobilenet_layer(opts, input_channel: int, cfg: Dict) -> Tuple[nn.Sequential, int]:
+        output_channels = cfg.get("out_channels")
+        block = []
+        for i in range(cfg.get("num_blocks", 2)):
+            stride = cfg.get("stride", 1) if i == 0 else 1
+            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=output_channels, stride=stride,
+                                          expand_ratio=cfg.get("expand_ratio", 4)))
+            input_channel = output_channels
+        return nn.Sequential(*block), input_channel
+
+    def _make_mit_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+        block = []
+        if cfg.get("stride", 1) == 2:
+            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=cfg.get("out_channels"), stride=2,
+                                          expand_ratio=cfg.get("mv_expand_ratio", 4), dilation=self.dilation))
+            input_channel = cfg.get("out_channels")
+        head_dim = cfg.get("head_dim", 32)
+        transformer_dim = cfg["transformer_channels"]
+        if head_dim is None:
+            num_heads = cfg.get("num_heads", 4) or 4
+            head_dim = transformer_dim // num_heads
+        if transformer_dim % head_dim != 0:
+            raise ValueError(f"Transformer input dimension should be divisible by head dimension. Got {transformer_dim} and {head_dim}.")
+        block.append(MobileViTBlock(
+            opts=opts, in_channels=input_channel, transformer_dim=transformer_dim, ffn_dim=cfg.get("ffn_dim"),
+            n_transformer_blocks=cfg.get("transformer_blocks", 1), patch_h=cfg.get("patch_h", 2), patch_w=cfg.get("patch_w", 2),
+            dropout=opt(opts, "model.classification.mit.dropout", 0.1), ffn_dropout=opt(opts, "model.classification.mit.ffn_dropout", 0.0),
+            attn_dropout=opt(opts, "model.classification.mit.attn_dropout", 0.1), head_dim=head_dim,
+            no_fusion=opt(opts, "model.classification.mit.no_fuse_local_global_features", False),
+            conv_ksize=opt(opts, "model.classification.mit.conv_kernel_size", 3)))
+        return nn.Sequential(*block), input_channel
+
+    # base_image_encoder.py:261-283
+    def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
+        if self.training:
+            ops.advance_dropout_seed(x.device)
+        x = ops.to_nhwc(x)
+        x = self.conv_1(x)
+        x = self.layer_1(x)
+        x = self.layer_2(x)
+        x = self.layer_3(x)
+        x = self.layer_4(x)
+        x = self.layer_5(x)
+        return self.conv_1x1_exp(x)
+
+    def forward_classifier(self, x: Tensor, *args, **kwargs) -> Tensor:
+        x = self.extract_features(x)
+        return self.classifier(x)
+
+    def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
+        return self.forward_classifier(x, *args, **kwargs)
+
+
+def build_mobilevit(mode: str = "small", opts=None, **overrides) -> MobileViT:
+    from .layers import default_opts
+
+    if opts is None:
+        opts = default_opts(**{"model.classification.mit.mode": mode}, **overrides)
+    return MobileViT(opts)

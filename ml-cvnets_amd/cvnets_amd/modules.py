@@ -1,0 +1,223 @@
+"""Host-side mirror of ``cvnets.modules`` for the hot path (InvertedResidual, TransformerEncoder, MobileViTBlock):
+same constructor signatures, attribute trees and state_dict keys as the reference; forward = HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .layers import (ConvLayer2d, Dropout, Identity, LayerNorm, LinearLayer, MultiHeadAttention, act_code, build_activation_layer,
+                     get_normalization_layer, opt)
+
+
+def make_divisible(v: Union[float, int], divisor: Optional[int] = 8, min_value: Optional[Union[float, int]] = None) -> Union[float, int]:
+    """cvnets/utils/math_utils.py make_divisible (used at cvnets/modules/mobilenetv2.py:176)."""
+    if min_value is None:
+        min_value = divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+class InvertedResidual(nn.Module):
+    """cvnets/modules/mobilenetv2.py:141-246: exp 1x1-BN-act -> depthwise 3x3-BN-act -> red 1x1-BN (+x)."""
+
+    def __init__(self, opts, in_channels: int, out_channels: int, stride: int, expand_ratio: Union[int, float], dilation: int = 1,
+                 skip_connection: Optional[bool] = True, *args, **kwargs) -> None:
+        assert stride in [1, 2]
+        hidden_dim = make_divisible(int(round(in_channels * expand_ratio)), 8)
+        super().__init__()
+        block = nn.Sequential()
+        if expand_ratio != 1:
+            block.add_module(name="exp_1x1", module=ConvLayer2d(opts, in_channels=in_channels, out_channels=hidden_dim, kernel_size=1,
+                                                                use_act=True, use_norm=True))
+        block.add_module(name="conv_3x3", module=ConvLayer2d(opts, in_channels=hidden_dim, out_channels=hidden_dim, stride=stride,
+                                                             kernel_size=3, groups=hidden_dim, use_act=True, use_norm=True, dilation=dilation))
+        block.add_module(name="red_1x1", module=ConvLayer2d(opts, in_channels=hidden_dim, out_channels=out_channels, kernel_size=1,
+                                                            use_act=False, use_norm=True))
+        self.block = block
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.exp = expand_ratio
+        self.dilation = dilation
+        self.stride = stride
+        self.use_res_connect = self.stride == 1 and in_channels == out_channels and skip_connection
+
+    def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
+        x = ops.to_nhwc(x)
+        y = x
+        mods = self.block._modules
+        if "exp_1x1" in mods:
+            y = mods["exp_1x1"](y)
+        y = mods["conv_3x3"](y)
+        # the residual add rides in the BN-apply pass of the projection conv
+        return mods["red_1x1"](y, residual=x if self.use_res_connect else None)
+
+    def __repr__(self) -> str:
+        return "{}(in_channels={}, out_channels={}, stride={}, exp={}, dilation={}, skip_conn={})".format(
+            self.__class__.__name__, self.in_channels, self.out_channels, self.stride, self.exp, self.dilation, self.use_res_connect)
+
+
+class TransformerEncoder(nn.Module):
+    """cvnets/modules/transformer.py:26-156 pre-norm block.  ``forward_tokens`` runs it on a [rows, C] token matrix whose
+    sequences are described by a seqmap (see ops.AttentionFn); ``forward`` is the reference's [B, S, C] signature."""
+
+    def __init__(self, opts, embed_dim: int, ffn_latent_dim: int, num_heads: Optional[int] = 8, attn_dropout: Optional[float] = 0.0,
+                 dropout: Optional[float] = 0.0, ffn_dropout: Optional[float] = 0.0, transformer_norm_layer: Optional[str] = "layer_norm",
+                 stochastic_dropout: Optional[float] = 0.0, *args, **kwargs) -> None:
+        super().__init__()
+        if num_heads <= 1:
+            raise NotImplementedError("SingleHeadAttention is not on the HIP hot path")
+        attn_unit = MultiHeadAttention(embed_dim, num_heads, attn_dropout=attn_dropout, bias=True,
+                                       coreml_compatible=opt(opts, "common.enable_coreml_compatible_module", False))
+        self.pre_norm_mha = nn.Sequential(
+            get_normalization_layer(opts=opts, norm_type=transformer_norm_layer, num_features=embed_dim),
+            attn_unit,
+            Dropout(p=dropout),
+        )
+        act_name = build_activation_layer(opts)
+        self.pre_norm_ffn = nn.Sequential(
+            get_normalization_layer(opts=opts, norm_type=transformer_norm_layer, num_features=embed_dim),
+            LinearLayer(in_features=embed_dim, out_features=ffn_latent_dim, bias=True),
+            act_name,
+            Dropout(p=ffn_dropout),
+            LinearLayer(in_features=ffn_latent_dim, out_features=embed_dim, bias=True),
+            Dropout(p=dropout),
+        )
+        self.drop_path = Identity()
+        if stochastic_dropout > 0.0:
+            raise NotImplementedError("StochasticDepth is not on the HIP hot path (reference MobileViT/ViT YAMLs use 0.0)")
+        self.embed_dim = embed_dim
+        self.ffn_dim = ffn_latent_dim
+        self.ffn_dropout = ffn_dropout
+        self.stochastic_dropout = stochastic_dropout
+        self.std_dropout = dropout
+        self.attn_fn_name = attn_unit.__class__.__name__
+        self.act_fn_name = act_name.__class__.__name__
+        self.norm_type = transformer_norm_layer
+
+    def __repr__(self) -> str:
+        return "{}(embed_dim={}, ffn_dim={}, dropout={}, ffn_dropout={}, stochastic_dropout={}, attn_fn={}, act_fn={}, norm_fn={})".format(
+            self.__class__.__name__, self.embed_dim, self.ffn_dim, self.std_dropout, self.ffn_dropout, self.stochastic_dropout,
+            self.attn_fn_name, self.act_fn_name, self.norm_type)
+
+    def forward_tokens(self, x: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None) -> Tensor:
+        ln1, mha, drop1 = self.pre_norm_mha[0], self.pre_norm_mha[1], self.pre_norm_mha[2]
+        ln2, fc1, act, drop_ffn, fc2, drop2 = (self.pre_norm_ffn[i] for i in range(6))
+        if not isinstance(ln1, nn.LayerNorm):
+            raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
+        p1 = drop1.p if self.training else 0.0
+        p2 = drop2.p if self.training else 0.0
+        if drop_ffn.p > 0.0 and self.training:
+            raise NotImplementedError("ffn_dropout > 0 is not fused (reference YAMLs use 0.0)")
+        # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue
+        y = ops.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
+        x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x)
+        # x = x + Dropout(W2 act(W1 LN(x)))
+        y = ops.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
+        h = ops.linear(y, fc1.weight, fc1.bias, act=act_code(act))
+        return ops.linear(h, fc2.weight, fc2.bias, drop_p=p2, residual=x)
+
+    def forward(self, x: Tensor, x_prev: Optional[Tensor] = None, key_padding_mask: Optional[Tensor] = None,
+                attn_mask: Optional[Tensor] = None, *args, **kwargs) -> Tensor:
+        if x_prev is not None:
+            raise NotImplementedError("cross-attention (x_prev) is not on the HIP hot path")
+        b, s, c = x.shape
+        causal = False
+        if attn_mask is not None:
+            from .layers import _mask_is_causal
+            causal = _mask_is_causal(attn_mask, b, s)
+        x2 = x.reshape(b * s, c)
+        if x2.dtype != ops.compute_dtype():
+            x2 = x2.to(ops.compute_dtype())
+        y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask)
+        return y.view(b, s, c)
+
+
+class MobileViTBlock(nn.Module):
+    """cvnets/modules/mobilevit_block.py:19-326.  local_rep (3x3 conv-BN-act, 1x1 conv) -> [unfold] -> L x TransformerEncoder
+    -> LayerNorm -> [fold] -> 1x1 conv-BN-act -> 3x3 fusion conv over cat(res, fm).  In NHWC the unfold/fold permutation is
+    pure addressing inside the attention kernel and the cat is two source pointers of the fusion conv — neither touches HBM."""
+
+    def __init__(self, opts, in_channels: int, transformer_dim: int, ffn_dim: int, n_transformer_blocks: Optional[int] = 2,
+                 head_dim: Optional[int] = 32, attn_dropout: Optional[float] = 0.0, dropout: Optional[int] = 0.0,
+                 ffn_dropout: Optional[int] = 0.0, patch_h: Optional[int] = 8, patch_w: Optional[int] = 8,
+                 transformer_norm_layer: Optional[str] = "layer_norm", conv_ksize: Optional[int] = 3, dilation: Optional[int] = 1,
+                 no_fusion: Optional[bool] = False, *args, **kwargs) -> None:
+        conv_3x3_in = ConvLayer2d(opts=opts, in_channels=in_channels, out_channels=in_channels, kernel_size=conv_ksize, stride=1,
+                                  use_norm=True, use_act=True, dilation=dilation)
+        conv_1x1_in = ConvLayer2d(opts=opts, in_channels=in_channels, out_channels=transformer_dim, kernel_size=1, stride=1,
+                                  use_norm=False, use_act=False)
+        conv_1x1_out = ConvLayer2d(opts=opts, in_channels=transformer_dim, out_channels=in_channels, kernel_size=1, stride=1,
+                                   use_norm=True, use_act=True)
+        conv_3x3_out = None
+        if not no_fusion:
+            conv_3x3_out = ConvLayer2d(opts=opts, in_channels=2 * in_channels, out_channels=in_channels, kernel_size=conv_ksize, stride=1,
+                                       use_norm=True, use_act=True)
+        super().__init__()
+        self.local_rep = nn.Sequential()
+        self.local_rep.add_module(name="conv_3x3", module=conv_3x3_in)
+        self.local_rep.add_module(name="conv_1x1", module=conv_1x1_in)
+        assert transformer_dim % head_dim == 0
+        num_heads = transformer_dim // head_dim
+        global_rep = [
+            TransformerEncoder(opts=opts, embed_dim=transformer_dim, ffn_latent_dim=ffn_dim, num_heads=num_heads, attn_dropout=attn_dropout,
+                               dropout=dropout, ffn_dropout=ffn_dropout, transformer_norm_layer=transformer_norm_layer)
+            for _ in range(n_transformer_blocks)
+        ]
+        global_rep.append(get_normalization_layer(opts=opts, norm_type=transformer_norm_layer, num_features=transformer_dim))
+        self.global_rep = nn.Sequential(*global_rep)
+        self.conv_proj = conv_1x1_out
+        self.fusion = conv_3x3_out
+        self.patch_h = patch_h
+        self.patch_w = patch_w
+        self.patch_area = self.patch_w * self.patch_h
+        self.cnn_in_dim = in_channels
+        self.cnn_out_dim = transformer_dim
+        self.n_heads = num_heads
+        self.ffn_dim = ffn_dim
+        self.dropout = dropout
+        self.attn_dropout = attn_dropout
+        self.ffn_dropout = ffn_dropout
+        self.dilation = dilation
+        self.n_blocks = n_transformer_blocks
+        self.conv_ksize = conv_ksize
+
+    def forward_spatial(self, x: Tensor) -> Tensor:
+        x = ops.to_nhwc(x)
+        res = x
+        fm = self.local_rep.conv_3x3(x)
+        fm = self.local_rep.conv_1x1(fm)
+        B, d, H, W = fm.shape
+        ph, pw = self.patch_h, self.patch_w
+        if H % ph or W % pw:
+            # reference: bilinear resize to a multiple of the patch (mobilevit_block.py:191-200, 260-266)
+            raise NotImplementedError(f"feature map {H}x{W} is not a multiple of the {ph}x{pw} patch: the bilinear-resize branch of "
+                                      "MobileViTBlock.unfolding is a 'next' row (SURVEY.md §8f) and has no HIP kernel yet")
+        n_h, n_w = H // ph, W // pw
+        seqmap = (B * ph * pw, n_h * n_w, ph, pw, n_w, H, W)
+        t = ops.tokens_of(fm)
+        for layer in self.global_rep:
+            if isinstance(layer, TransformerEncoder):
+                t = layer.forward_tokens(t, seqmap)
+            else:
+                if not isinstance(layer, nn.LayerNorm):
+                    raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
+                t = ops.layer_norm(t, layer.weight, layer.bias, layer.eps)
+        fm = ops.fmap_of(t, B, H, W)
+        fm = self.conv_proj(fm)
+        if self.fusion is not None:
+            fm = self.fusion(res, x2=fm)  # conv over cat(res, fm) without materialising the cat
+        return fm
+
+    def forward(self, x: Union[Tensor, Tuple[Tensor]], *args, **kwargs) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        if isinstance(x, Tuple) and len(x) == 2:
+            raise NotImplementedError("spatio-temporal MobileViT (forward_temporal) is not on the HIP hot path")
+        if isinstance(x, Tensor):
+            return self.forward_spatial(x)
+        raise NotImplementedError

@@ -1,0 +1,620 @@
+"""Autograd operators of the hot path: thin torch.autograd.Function wrappers that enqueue the HIP kernels
+of libcvnets_hip.so (through ctypes, on torch's current stream) for forward AND backward.
+
+PyTorch is used here only for device memory (torch.empty -> caching allocator), stream identity and the
+autograd graph; no ATen compute kernel is on the path (exceptions, all off the per-element path, are marked
+"plumbing": zero-fills of parameter-gradient buffers and tiny constant vectors).
+
+Tensor conventions
+  * feature maps: logical [B, C, H, W] torch tensors whose memory is NHWC (channels_last strides), dtype =
+    compute dtype (float32 or bfloat16), C % 8 == 0;
+  * token matrices: contiguous [rows, C];
+  * parameters / statistics / parameter gradients: float32 in torch's own layouts.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+_COMPUTE_DTYPE: Optional[torch.dtype] = None
+
+
+def set_compute_dtype(dtype: Optional[torch.dtype]) -> None:
+    """float32 / bfloat16, or None = follow torch autocast (bf16 under autocast(bfloat16), else fp32) — the
+    behaviour of the reference under engine/utils.py:19-36 autocast_fn."""
+    global _COMPUTE_DTYPE
+    assert dtype in (None, torch.float32, torch.bfloat16)
+    _COMPUTE_DTYPE = dtype
+
+
+def compute_dtype() -> torch.dtype:
+    if _COMPUTE_DTYPE is not None:
+        return _COMPUTE_DTYPE
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        if dt == torch.bfloat16:
+            return torch.bfloat16
+        raise RuntimeError("cvnets_amd supports bfloat16 autocast only (set common.mixed_precision_dtype=bfloat16)")
+    return torch.float32
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise RuntimeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("cvnets_amd ops run on the GPU only (HIP kernels; there is no CPU fallback)")
+
+
+def _f32(n, device, *shape):
+    return torch.empty((n, *shape) if shape else (n,), dtype=torch.float32, device=device)
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------
+def nhwc_empty(B, C, H, W, dtype, device) -> torch.Tensor:
+    return torch.empty((B, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def is_nhwc(x: torch.Tensor) -> bool:
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def as_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Gradient tensors handed to us by autograd are normally already NHWC; otherwise repack (plumbing)."""
+    if is_nhwc(x):
+        return x
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def tokens_of(x: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] NHWC feature map -> its [B*H*W, C] token matrix (a view)."""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def fmap_of(t: torch.Tensor, B, H, W) -> torch.Tensor:
+    return t.view(B, H, W, t.shape[-1]).permute(0, 3, 1, 2)
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, dtype: torch.dtype):
+        _check_dev(x)
+        B, C, H, W = x.shape
+        Cp = pad8(C)
+        ctx.meta = (B, C, H, W, Cp)
+        xin = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()  # plumbing
+        out = nhwc_empty(B, Cp, H, W, dtype, x.device)
+        _lib.call("cvh_nchw_to_nhwc", _dt(out), _p(xin), _p(out), B, C, H, W, Cp, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W, Cp = ctx.meta
+        g = as_nhwc(g)
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+        _lib.call("cvh_nhwc_to_nchw", _dt(g), _p(g), _p(dx), B, C, H, W, Cp, _stream())
+        return dx, None
+
+
+def to_nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Entry of the hot path: NCHW float32 image batch -> NHWC compute-dtype tensor (channels padded to 8)."""
+    dtype = dtype or compute_dtype()
+    if x.dtype == dtype and is_nhwc(x) and x.shape[1] % 8 == 0:
+        return x
+    return _ToNHWC.apply(x, dtype)
+
+
+def nhwc_to_nchw_f32(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
+    B, Cs, H, W = x.shape
+    C = C or Cs
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _lib.call("cvh_nhwc_to_nchw", _dt(x), _p(x), _p(out), B, C, H, W, Cs, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout state: one device-resident 64-bit seed per device; masks are f(seed, stream_id, element)
+# ------------------------------------------------------------------------------------------------
+_seeds = {}
+_stream_ids = itertools.count(1)
+
+
+def dropout_seed(device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    if key not in _seeds:
+        _seeds[key] = torch.tensor([0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device) + torch.initial_seed()
+    return _seeds[key]
+
+
+def advance_dropout_seed(device) -> None:
+    """Called once at the start of every training forward (captured into the step's hipGraph, so replays draw
+    fresh masks)."""
+    _lib.call("cvh_seed_advance", _p(dropout_seed(device)), _stream())
+
+
+def next_stream_id() -> int:
+    return next(_stream_ids) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing
+# ------------------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, mode: int) -> torch.Tensor:
+    """mode 0: [Cout][KH*KW][pad8(Cin)] ; mode 1: [Cin][KH*KW][pad8(Cout)] (taps flipped) ; mode 2: depthwise [KH*KW][C]."""
+    wf = w.detach()
+    if wf.dtype != torch.float32 or not wf.is_contiguous():
+        wf = wf.float().contiguous()  # plumbing (parameters are fp32 contiguous in practice)
+    if wf.dim() == 2:
+        Cout, Cin, KHW = wf.shape[0], wf.shape[1], 1
+    else:
+        Cout, Cin, KHW = wf.shape[0], wf.shape[1], wf.shape[2] * wf.shape[3]
+    if mode == 0:
+        n = Cout * KHW * pad8(Cin)
+    elif mode == 1:
+        n = Cin * KHW * pad8(Cout)
+    else:
+        n = KHW * Cout
+    out = torch.empty(n, dtype=dtype, device=w.device)
+    _lib.call("cvh_weight_pack", _dt(out), _p(wf), _p(out), Cout, Cin, KHW, mode, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# low-level launch helpers
+# ------------------------------------------------------------------------------------------------
+def _conv_gemm(src1, src2, C1, C2, wp, out, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, bias=None, act=0, save_pre=None,
+               actgrad_aux=None, actgrad_act=0, residual=None, drop_p=0.0, seed=None, stream_id=0, stats_part=None, wp_offset=0):
+    wptr = wp.data_ptr() + wp_offset * wp.element_size()
+    _lib.call("cvh_conv_gemm", _dt(out), _p(src1), _p(src2), C1, C2, wptr, _p(out), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N,
+              _p(bias), act, _p(save_pre), _p(actgrad_aux), actgrad_act, _p(residual), float(drop_p), _p(seed), stream_id,
+              _p(stats_part), _stream())
+
+
+def _unit_coeffs(C, device):
+    ones = torch.ones(C, dtype=torch.float32, device=device)  # plumbing: tiny constant vectors
+    zeros = torch.zeros(C, dtype=torch.float32, device=device)
+    return ones, zeros
+
+
+def _act_backward(pre: torch.Tensor, dout: torch.Tensor, act: int, rows: int, C: int) -> torch.Tensor:
+    """dpre = dout * act'(pre)  (BatchNorm-backward apply kernel with identity normalisation)."""
+    ones, zeros = _unit_coeffs(C, pre.device)
+    dx = torch.empty_like(dout)
+    _lib.call("cvh_bn_bwd_apply", _dt(pre), _p(pre), _p(dout), _p(ones), _p(zeros), act, _p(ones), _p(zeros), _p(zeros), _p(dx), rows, C,
+              _stream())
+    return dx
+
+
+def _colsum(x2d: torch.Tensor, rows: int, C: int) -> torch.Tensor:
+    R = _lib.query("cvh_colreduce_rows", rows, C)
+    part = _f32(R * 2 * C, x2d.device)
+    out = _f32(C, x2d.device)
+    _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), _p(out), 1.0, _stream())
+    return out
+
+
+def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentum, eps):
+    """returns stats [4][C] = (mean, invstd, scale, shift)."""
+    stats = _f32(4, y.device, C)
+    if training:
+        _lib.call("cvh_bn_finalize", _p(part), R, C, float(rows), _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps),
+                  _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _stream())
+    else:
+        _lib.call("cvh_bn_eval_coeff", _p(gamma), _p(beta), _p(rmean), _p(rvar), float(eps), C, _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                  _p(stats[3]), _stream())
+    return stats
+
+
+def _bn_backward(y, dout, stats, gamma, act, rows, C, training, need_affine_grads=True):
+    """returns (dy_raw, dgamma, dbeta)."""
+    dev = y.device
+    R = _lib.query("cvh_colreduce_rows", rows, C)
+    part = _f32(R * 2 * C, dev)
+    _lib.call("cvh_bn_bwd_reduce", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), act, rows, C, _p(part),
+              _stream())
+    dgamma = _f32(C, dev)
+    dbeta = _f32(C, dev)
+    coeff = _f32(3, dev, C)
+    _lib.call("cvh_bn_bwd_finalize", _p(part), R, C, float(rows), _p(gamma), _p(stats[0]), _p(stats[1]), 1 if training else 0, _p(dgamma),
+              _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
+    dy = torch.empty_like(y)
+    _lib.call("cvh_bn_bwd_apply", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), act, _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _p(dy),
+              rows, C, _stream())
+    return dy, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# dense conv (+BatchNorm +activation +residual), optional channel-concat of two inputs
+# ------------------------------------------------------------------------------------------------
+class ConvBNAct(torch.autograd.Function):
+    """ConvLayer2d.forward for groups == 1 (cvnets/layers/conv_layer.py:254-255): conv -> BN(train/eval) -> act,
+    plus the residual add / channel concat that surround it in InvertedResidual / MobileViTBlock."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, gamma, beta, rmean, rvar, residual, cfg):
+        stride, pad, dil, act, use_bn, training, momentum, eps = cfg
+        _check_dev(x)
+        B, C1, H, W = x.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        Cout, Cin_real, KH, KW = weight.shape
+        if pad8(Cin_real) != C1 + C2:
+            raise RuntimeError(f"conv input has {C1 + C2} (padded) channels, weight expects {Cin_real}")
+        if Cout % 8:
+            raise RuntimeError("cvnets_amd convs need out_channels % 8 == 0")
+        Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+        M = B * Ho * Wo
+        dev, dtype = x.device, x.dtype
+        wp = pack_weight(weight, dtype, 0)
+        y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        ctx.cfg = cfg
+        ctx.shapes = (B, C1, C2, H, W, Ho, Wo, Cout, Cin_real, KH, KW)
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        if use_bn:
+            part, R = None, 0
+            if training:
+                R = _lib.query("cvh_conv_gemm_grid_rows", M, Cout)
+                part = _f32(R * 2 * Cout, dev)
+            _conv_gemm(x, x2, C1, C2, wp, y, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, bias=bias, stats_part=part)
+            stats = _bn_forward(y, M, Cout, part, R, gamma, beta, rmean, rvar, training, momentum, eps)
+            out = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+            _lib.call("cvh_bn_apply", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, _p(residual), _p(out), M, Cout, _stream())
+            ctx.save_for_backward(x, x2, weight, y, stats, gamma)
+            return out
+        pre = nhwc_empty(B, Cout, Ho, Wo, dtype, dev) if act != ACT_NONE else None
+        _conv_gemm(x, x2, C1, C2, wp, y, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, bias=bias, act=act, save_pre=pre, residual=residual)
+        ctx.save_for_backward(x, x2, weight, pre, None, None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        stride, pad, dil, act, use_bn, training, momentum, eps = ctx.cfg
+        B, C1, C2, H, W, Ho, Wo, Cout, Cin_real, KH, KW = ctx.shapes
+        x, x2, weight, y, stats, gamma = ctx.saved_tensors
+        dout = as_nhwc(dout)
+        M = B * Ho * Wo
+        dev, dtype = dout.device, dout.dtype
+        dgamma = dbeta = dbias = None
+        if use_bn:
+            dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, Cout, training)
+        elif act != ACT_NONE:
+            dy = _act_backward(y, dout, act, M, Cout)
+        else:
+            dy = dout
+        if ctx.has_bias:
+            dbias = _colsum(dy, M, Cout)
+        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing: zero-fill for the atomic accumulation
+        _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real,
+                  _stream())
+        dx = dx2 = None
+        need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
+        if need1 or need2:
+            if stride != 1:
+                raise NotImplementedError("dX of a strided dense conv is not on the hot path (only the stem is strided)")
+            wpt = pack_weight(weight, dtype, 1)  # [Cin][KH*KW][Cout]
+            pad_t = dil * (KH - 1) - pad
+            kk = KH * KW * Cout
+            if need1:
+                dx = nhwc_empty(B, C1, H, W, dtype, dev)
+                _conv_gemm(dy, None, Cout, 0, wpt, dx, B, Ho, Wo, H, W, KH, KW, 1, pad_t, dil, C1)
+            if need2:
+                dx2 = nhwc_empty(B, C2, H, W, dtype, dev)
+                _conv_gemm(dy, None, Cout, 0, wpt, dx2, B, Ho, Wo, H, W, KH, KW, 1, pad_t, dil, C2, wp_offset=C1 * kk)
+        dres = dout if ctx.has_res else None
+        return dx, dx2, dw, dbias, dgamma, dbeta, None, None, dres, None
+
+
+def conv_bn_act(x, weight, bias=None, gamma=None, beta=None, rmean=None, rvar=None, *, stride=1, pad=0, dil=1, act=ACT_NONE,
+                use_bn=False, training=True, momentum=0.1, eps=1e-5, residual=None, x2=None):
+    cfg = (int(stride), int(pad), int(dil), int(act), bool(use_bn), bool(training), float(momentum), float(eps))
+    return ConvBNAct.apply(x, x2, weight, bias, gamma, beta, rmean, rvar, residual, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# depthwise conv (+BatchNorm +activation)
+# ------------------------------------------------------------------------------------------------
+class DWConvBNAct(torch.autograd.Function):
+    """ConvLayer2d.forward with groups == C (InvertedResidual.conv_3x3, cvnets/modules/mobilenetv2.py:194-207)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, rmean, rvar, cfg):
+        stride, pad, dil, act, use_bn, training, momentum, eps = cfg
+        _check_dev(x)
+        B, C, H, W = x.shape
+        K = weight.shape[-1]
+        Ho = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        M = B * Ho * Wo
+        dev, dtype = x.device, x.dtype
+        wp = pack_weight(weight, dtype, 2)
+        y = nhwc_empty(B, C, Ho, Wo, dtype, dev)
+        ctx.cfg = cfg
+        ctx.shapes = (B, C, H, W, Ho, Wo, K)
+        part, R = None, 0
+        if use_bn and training:
+            R = _lib.query("cvh_dwconv_rows", B, Ho, Wo, C)
+            part = _f32(R * 2 * C, dev)
+        _lib.call("cvh_dwconv_fwd", _dt(x), _p(x), _p(wp), _p(y), B, H, W, Ho, Wo, C, K, stride, pad, dil, _p(part), _stream())
+        if not use_bn:
+            if act != ACT_NONE:
+                raise NotImplementedError("depthwise conv + activation without normalisation")
+            ctx.save_for_backward(x, weight, None, None, None)
+            return y
+        stats = _bn_forward(y, M, C, part, R, gamma, beta, rmean, rvar, training, momentum, eps)
+        out = nhwc_empty(B, C, Ho, Wo, dtype, dev)
+        _lib.call("cvh_bn_apply", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, None, _p(out), M, C, _stream())
+        ctx.save_for_backward(x, weight, y, stats, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        stride, pad, dil, act, use_bn, training, momentum, eps = ctx.cfg
+        B, C, H, W, Ho, Wo, K = ctx.shapes
+        x, weight, y, stats, gamma = ctx.saved_tensors
+        dout = as_nhwc(dout)
+        dev, dtype = dout.device, dout.dtype
+        M = B * Ho * Wo
+        dgamma = dbeta = None
+        if use_bn:
+            dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, C, training)
+        else:
+            dy = dout
+        R = _lib.query("cvh_dwconv_bwd_w_rows", B, Ho, Wo, C)
+        part = _f32(R * C * K * K, dev)
+        _lib.call("cvh_dwconv_bwd_w", _dt(x), _p(x), _p(dy), _p(part), B, H, W, Ho, Wo, C, K, stride, pad, dil, _stream())
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        _lib.call("cvh_sum_partials", _p(part), R, C * K * K, _p(dw), 1.0, _stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wp = pack_weight(weight, dtype, 2)
+            dx = nhwc_empty(B, C, H, W, dtype, dev)
+            _lib.call("cvh_dwconv_bwd_x", _dt(dy), _p(dy), _p(wp), _p(dx), B, H, W, Ho, Wo, C, K, stride, pad, dil, _stream())
+        return dx, dw, dgamma, dbeta, None, None, None
+
+
+def dwconv_bn_act(x, weight, gamma=None, beta=None, rmean=None, rvar=None, *, stride=1, pad=1, dil=1, act=ACT_NONE, use_bn=True,
+                  training=True, momentum=0.1, eps=1e-5):
+    cfg = (int(stride), int(pad), int(dil), int(act), bool(use_bn), bool(training), float(momentum), float(eps))
+    return DWConvBNAct.apply(x, weight, gamma, beta, rmean, rvar, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# standalone BatchNorm (+act): used when a norm layer is called outside a ConvLayer2d
+# ------------------------------------------------------------------------------------------------
+class BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, cfg):
+        act, training, momentum, eps = cfg
+        _check_dev(x)
+        B, C, H, W = x.shape
+        M = B * H * W
+        part, R = None, 0
+        if training:
+            R = _lib.query("cvh_colreduce_rows", M, C)
+            part = _f32(R * 2 * C, x.device)
+            _lib.call("cvh_bn_stats", _dt(x), _p(x), M, C, _p(part), _stream())
+        stats = _bn_forward(x, M, C, part, R, gamma, beta, rmean, rvar, training, momentum, eps)
+        out = torch.empty_like(x)
+        _lib.call("cvh_bn_apply", _dt(x), _p(x), _p(stats[2]), _p(stats[3]), act, None, _p(out), M, C, _stream())
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, stats, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        act, training, momentum, eps = ctx.cfg
+        x, stats, gamma = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dx, dgamma, dbeta = _bn_backward(x, as_nhwc(dout), stats, gamma, act, B * H * W, C, training)
+        return dx, dgamma, dbeta, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# linear on token matrices (+bias +act +dropout +residual)
+# ------------------------------------------------------------------------------------------------
+class LinearAct(torch.autograd.Function):
+    """LinearLayer.forward = F.linear (cvnets/layers/linear_layer.py:74-91) with the activation / Dropout / residual
+    add that follow it in TransformerEncoder (cvnets/modules/transformer.py:140-155) fused into the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, cfg):
+        act, drop_p, stream_id = cfg
+        _check_dev(x)
+        rows, K = x.shape
+        N = weight.shape[0]
+        if K % 8 or N % 8:
+            raise RuntimeError("cvnets_amd linear layers need in/out features % 8 == 0")
+        dev, dtype = x.device, x.dtype
+        wp = pack_weight(weight, dtype, 0)
+        out = torch.empty((rows, N), dtype=dtype, device=dev)
+        pre = torch.empty((rows, N), dtype=dtype, device=dev) if act != ACT_NONE else None
+        seed = dropout_seed(dev) if drop_p > 0 else None
+        _conv_gemm(x, None, K, 0, wp, out, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, bias=bias, act=act, save_pre=pre, residual=residual,
+                   drop_p=drop_p, seed=seed, stream_id=stream_id)
+        ctx.cfg = cfg
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        act, drop_p, stream_id = ctx.cfg
+        x, weight, pre = ctx.saved_tensors
+        rows, K = x.shape
+        N = weight.shape[0]
+        dev, dtype = dout.device, dout.dtype
+        dout = dout.contiguous()
+        dy = dout
+        if drop_p > 0:
+            dy = torch.empty_like(dout)
+            _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(dropout_seed(dev)), stream_id, _stream())
+        if act != ACT_NONE:
+            dy = _act_backward(pre, dy, act, rows, N)
+        dbias = _colsum(dy, rows, N) if ctx.has_bias else None
+        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing
+        _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), None, K, 0, _p(dw), rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K, _stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpt = pack_weight(weight, dtype, 1)  # [K][N]
+            dx = torch.empty((rows, K), dtype=dtype, device=dev)
+            _conv_gemm(dy, None, N, 0, wpt, dx, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, K)
+        dres = dout if ctx.has_res else None
+        return dx, dw, dbias, dres, None
+
+
+def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None):
+    sid = next_stream_id() if drop_p > 0 else 0
+    return LinearAct.apply(x2d, weight, bias, residual, (int(act), float(drop_p), sid))
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm over the last dim of a token matrix
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _check_dev(x)
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        mr = _f32(2, x.device, rows)
+        _lib.call("cvh_layernorm_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mr[0]), _p(mr[1]), rows, C, float(eps), _stream())
+        ctx.save_for_backward(x, gamma, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, mr = ctx.saved_tensors
+        rows, C = x.shape
+        dout = dout.contiguous()
+        R = _lib.query("cvh_ln_bwd_rows", rows)
+        part = _f32(R * 2 * C, x.device)
+        dx = torch.empty_like(x)
+        _lib.call("cvh_layernorm_bwd", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _stream())
+        dgb = _f32(2 * C, x.device)
+        _lib.call("cvh_sum_partials", _p(part), R, 2 * C, _p(dgb), 1.0, _stream())
+        return dx, dgb[:C], dgb[C:], None
+
+
+def layer_norm(x2d, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x2d, gamma, beta, float(eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused multi-head self-attention on the qkv token matrix
+# ------------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """MultiHeadAttention.forward_default lines 148-233 (cvnets/layers/multi_head_attention.py) between the two
+    projections; `seqmap` = (nseq, S, ph, pw, n_w, H, W) realises MobileViTBlock.unfolding/folding by addressing."""
+
+    @staticmethod
+    def forward(ctx, qkv, kpm, cfg):
+        heads, seqmap, causal = cfg
+        nseq, S, ph, pw, n_w, H, W = seqmap
+        _check_dev(qkv)
+        rows, d3 = qkv.shape
+        d = d3 // 3
+        c = d // heads
+        if c > 64:
+            raise NotImplementedError("head_dim > 64")
+        out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
+        lse = _f32(nseq * heads * S, qkv.device)
+        _lib.call("cvh_attn_fwd", _dt(qkv), _p(qkv), _p(out), _p(lse), _p(kpm), nseq, S, heads, c, ph, pw, n_w, H, W, float(c) ** -0.5,
+                  1 if causal else 0, _stream())
+        ctx.cfg = cfg
+        ctx.save_for_backward(qkv, out, lse, kpm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        heads, seqmap, causal = ctx.cfg
+        nseq, S, ph, pw, n_w, H, W = seqmap
+        qkv, out, lse, kpm = ctx.saved_tensors
+        d = qkv.shape[1] // 3
+        c = d // heads
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dsum = _f32(nseq * heads * S, qkv.device)
+        _lib.call("cvh_attn_bwd", _dt(qkv), _p(qkv), _p(out), _p(dout), _p(dqkv), _p(lse), _p(dsum), _p(kpm), nseq, S, heads, c, ph, pw, n_w,
+                  H, W, float(c) ** -0.5, 1 if causal else 0, _stream())
+        return dqkv, None, None
+
+
+def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None):
+    kpm = None
+    if key_padding_mask is not None:
+        kpm = key_padding_mask.to(torch.uint8).contiguous()  # plumbing
+    return AttentionFn.apply(qkv2d, kpm, (int(heads), tuple(int(v) for v in seqmap), bool(causal)))
+
+
+# ------------------------------------------------------------------------------------------------
+# global average pool
+# ------------------------------------------------------------------------------------------------
+class GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check_dev(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C), dtype=x.dtype, device=x.device)
+        _lib.call("cvh_pool_fwd", _dt(x), _p(x), _p(y), B, H * W, C, _stream())
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = dy.contiguous()
+        dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
+        _lib.call("cvh_pool_bwd", _dt(dy), _p(dy), _p(dx), B, H * W, C, _stream())
+        return dx
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, stream_id):
+        _check_dev(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.call("cvh_dropout", _dt(x), _p(x), _p(y), x.numel(), float(p), _p(dropout_seed(x.device)), stream_id, _stream())
+        ctx.cfg = (p, stream_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, stream_id = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.call("cvh_dropout", _dt(dy), _p(dy), _p(dx), dy.numel(), float(p), _p(dropout_seed(dy.device)), stream_id, _stream())
+        return dx, None, None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p), next_stream_id())

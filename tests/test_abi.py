@@ -1,0 +1,69 @@
+"""CPU test: libcvnets_hip.so loads and exports every symbol declared in include/cvnets_hip.h, and the ctypes
+prototypes in cvnets_amd/_lib.py agree with the header argument-for-argument (no compute calls — no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "cvnets_hip.h")
+
+CT = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
+      "unsigned int": ctypes.c_uint}
+
+
+def header_prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(cvh_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2)
+        types = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if "*" in a:
+                types.append(ctypes.c_void_p)
+            else:
+                t = " ".join(a.split(" ")[:-1])
+                types.append(CT[t])
+        protos[name] = types
+    return protos
+
+
+def test_header_matches_ctypes_table():
+    from cvnets_amd import _lib
+    protos = header_prototypes()
+    assert len(protos) >= 30
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    for name, types in protos.items():
+        assert types == _lib.SIGNATURES[name], name
+
+
+def test_library_exports_every_declared_symbol():
+    from cvnets_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import subprocess
+        import sys
+        subprocess.check_call([sys.executable, os.path.join(REPO, "ml-cvnets_amd", "build.py")])
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_prototypes():
+        assert hasattr(lib, name), name
+    # size-query entry points are host-only and safe to call without a GPU
+    assert _lib.query("cvh_conv_gemm_grid_rows", 128 * 128 * 64, 64) == 2048
+    assert _lib.query("cvh_colreduce_rows", 1000, 144) > 0
+    assert _lib.query("cvh_ln_bwd_rows", 1000) == 63
+    with pytest.raises(RuntimeError):
+        _lib.query("cvh_colreduce_rows", 1000, 20)  # C % 8 != 0 is rejected
+
+
+def test_ops_refuse_to_run_without_gpu():
+    """the product path has no CPU fallback: calling an op on CPU tensors raises instead of silently computing."""
+    import torch
+    from cvnets_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(8, 8), torch.zeros(8, 8))
+    with pytest.raises(RuntimeError):
+        ops.to_nhwc(torch.zeros(1, 3, 4, 4))

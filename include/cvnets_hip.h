@@ -107,6 +107,11 @@ int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const u
 int cvh_seed_advance(unsigned long long* seed, void* stream);
 int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void* stream);
 
+/* F.interpolate(mode="bilinear", align_corners=False) of MobileViTBlock.unfolding/folding for feature maps that are not a
+ * multiple of the patch (cvnets/modules/mobilevit_block.py:191-200, 260-266); bwd = exact adjoint (gather form). */
+int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, void* stream);
+int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, void* stream);
+
 /* ---- LayerNorm over channels -------------------------------------------------------------------- */
 /* Replaces nn.LayerNorm, channel-last branch (cvnets/layers/normalization/layer_norm.py:67-68). */
 int cvh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

@@ -387,6 +387,93 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False (F.interpolate in MobileViTBlock.unfolding/folding when the map is not a
+// multiple of the patch: cvnets/modules/mobilevit_block.py:191-200, 260-266).  Same arithmetic as ATen's
+// upsample_bilinear2d: src = scale*(dst+0.5)-0.5 clamped at 0, i1 = min(i0+1, in-1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilin_src(int o, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+template <typename T>
+__global__ void resize_bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int Ho, int Wo, int C) {
+  const int cgs = C / 8;
+  const size_t total = (size_t)B * Ho * Wo * cgs;
+  const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cgs);
+    size_t t = idx / cgs;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const size_t b = t / Ho;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bilin_src(oy, sh, H, y0, y1, ly0, ly1);
+    bilin_src(ox, sw, W, x0, x1, lx0, lx1);
+    float p00[8], p01[8], p10[8], p11[8], o[8];
+    v8_unpack(v8_load<T>(x + ((b * H + y0) * W + x0) * C + cg * 8), p00);
+    v8_unpack(v8_load<T>(x + ((b * H + y0) * W + x1) * C + cg * 8), p01);
+    v8_unpack(v8_load<T>(x + ((b * H + y1) * W + x0) * C + cg * 8), p10);
+    v8_unpack(v8_load<T>(x + ((b * H + y1) * W + x1) * C + cg * 8), p11);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ly0 * (lx0 * p00[j] + lx1 * p01[j]) + ly1 * (lx0 * p10[j] + lx1 * p11[j]);
+    V8<T> ov;
+    v8_pack(o, ov);
+    v8_store<T>(y + idx * 8, ov);
+  }
+}
+
+// gather-form backward: every input pixel sums the output pixels that sampled it (deterministic, no atomics)
+template <typename T>
+__global__ void resize_bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int Ho, int Wo, int C) {
+  const int cgs = C / 8;
+  const size_t total = (size_t)B * H * W * cgs;
+  const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % cgs);
+    size_t t = idx / cgs;
+    const int ix = (int)(t % W);
+    t /= W;
+    const int iy = (int)(t % H);
+    const size_t b = t / H;
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+    ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      bilin_src(oy, sh, H, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        bilin_src(ox, sw, W, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        float d[8];
+        v8_unpack(v8_load<T>(dy + ((b * Ho + oy) * Wo + ox) * C + cg * 8), d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy * wx * d[j];
+      }
+    }
+    V8<T> ov;
+    v8_pack(acc, ov);
+    v8_store<T>(dx + idx * 8, ov);
+  }
+}
+
 __global__ void seed_advance_kernel(unsigned long long* seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
 
 // =============================================================================================
@@ -539,6 +626,22 @@ extern "C" int cvh_add(int dtype, const void* a, const void* b, void* y, long lo
 }
 extern "C" int cvh_seed_advance(unsigned long long* seed, void* stream) {
   hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, seed);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, void* stream) {
+  if (C % 8) return -2;
+  size_t total = (size_t)B * Ho * Wo * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_bilinear_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, Ho, Wo, C);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+/* dx[B][H][W][C] = adjoint of the (H,W)->(Ho,Wo) resize applied to dy[B][Ho][Wo][C] */
+extern "C" int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, void* stream) {
+  if (C % 8) return -2;
+  size_t total = (size_t)B * H * W * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_bilinear_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, H, W, Ho, Wo, C);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

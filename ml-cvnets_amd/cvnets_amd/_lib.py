@@ -49,6 +49,8 @@ SIGNATURES = {
     "cvh_dropout": [I, P, P, L, F, P, U, P],
     "cvh_seed_advance": [P, P],
     "cvh_add": [I, P, P, P, L, P],
+    "cvh_resize_bilinear_fwd": [I, P, P, I, I, I, I, I, I, P],
+    "cvh_resize_bilinear_bwd": [I, P, P, I, I, I, I, I, I, P],
     "cvh_layernorm_fwd": [I, P, P, P, P, P, P, L, I, F, P],
     "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
     "cvh_ln_bwd_rows": [L],

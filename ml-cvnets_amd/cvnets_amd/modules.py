@@ -195,10 +195,11 @@ class MobileViTBlock(nn.Module):
         fm = self.local_rep.conv_1x1(fm)
         B, d, H, W = fm.shape
         ph, pw = self.patch_h, self.patch_w
-        if H % ph or W % pw:
-            # reference: bilinear resize to a multiple of the patch (mobilevit_block.py:191-200, 260-266)
-            raise NotImplementedError(f"feature map {H}x{W} is not a multiple of the {ph}x{pw} patch: the bilinear-resize branch of "
-                                      "MobileViTBlock.unfolding is a 'next' row (SURVEY.md §8f) and has no HIP kernel yet")
+        Hn, Wn = int(math.ceil(H / ph) * ph), int(math.ceil(W / pw) * pw)
+        interpolate = (Hn != H) or (Wn != W)
+        if interpolate:  # reference: bilinear resize to a multiple of the patch (mobilevit_block.py:191-200)
+            fm = ops.resize_bilinear(fm, Hn, Wn)
+        H0, W0, H, W = H, W, Hn, Wn
         n_h, n_w = H // ph, W // pw
         seqmap = (B * ph * pw, n_h * n_w, ph, pw, n_w, H, W)
         t = ops.tokens_of(fm)
@@ -210,6 +211,8 @@ class MobileViTBlock(nn.Module):
                     raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
                 t = ops.layer_norm(t, layer.weight, layer.bias, layer.eps)
         fm = ops.fmap_of(t, B, H, W)
+        if interpolate:  # ... and back to the original size after folding (mobilevit_block.py:260-266)
+            fm = ops.resize_bilinear(fm, H0, W0)
         fm = self.conv_proj(fm)
         if self.fusion is not None:
             fm = self.fusion(res, x2=fm)  # conv over cat(res, fm) without materialising the cat

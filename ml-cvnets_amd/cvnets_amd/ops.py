@@ -595,6 +595,31 @@ class GlobalAvgPool(torch.autograd.Function):
         return dx
 
 
+class ResizeBilinear(torch.autograd.Function):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) on an NHWC map (mobilevit_block.py:191-200, 260-266)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        _check_dev(x)
+        B, C, H, W = x.shape
+        y = nhwc_empty(B, C, Ho, Wo, x.dtype, x.device)
+        _lib.call("cvh_resize_bilinear_fwd", _dt(x), _p(x), _p(y), B, H, W, Ho, Wo, C, _stream())
+        ctx.shape = (B, C, H, W, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, Ho, Wo = ctx.shape
+        dy = as_nhwc(dy)
+        dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
+        _lib.call("cvh_resize_bilinear_bwd", _dt(dy), _p(dy), _p(dx), B, H, W, Ho, Wo, C, _stream())
+        return dx, None, None
+
+
+def resize_bilinear(x, Ho: int, Wo: int):
+    return ResizeBilinear.apply(x, int(Ho), int(Wo))
+
+
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, stream_id):

@@ -127,7 +127,7 @@ def test_conv_bn_act(ops, dtype, B, Cin, H, W, Cout, k, stride, dil, use_bn):
     gr, ber = g.detach().clone().requires_grad_(True), be.detach().clone().requires_grad_(True)
     if use_bn:
         if dtype == torch.bfloat16:
-            c = c.to(dtype).float() + (c - c.detach())  # BN sees the conv output as stored (bf16), gradient straight-through
+            c = c + (c.to(dtype).float() - c).detach()  # BN sees the conv output as stored (bf16), gradient straight-through
         c = F.batch_norm(c, rm0, rv0, gr, ber, training=True, momentum=0.1, eps=1e-5)
     ref = F.silu(c)
     assert ops.is_nhwc(y)
@@ -179,7 +179,7 @@ def test_conv_concat_residual(ops, dtype):
     gr, ber = g.detach().clone().requires_grad_(True), be.detach().clone().requires_grad_(True)
     c = F.conv2d(torch.cat((ar, br), 1), wr, None, padding=1)
     if dtype == torch.bfloat16:
-        c = c.to(dtype).float() + (c - c.detach())
+        c = c + (c.to(dtype).float() - c).detach()
     ref = F.batch_norm(c, None, None, gr, ber, training=True) + rr
     check("concat conv fwd", y, ref, dtype)
     go = nhwc(_rand(*y.shape, seed=7), dtype)
@@ -224,7 +224,7 @@ def test_dwconv_bn_act(ops, dtype, B, C, H, W, stride, dil):
     gr, ber = g.detach().clone().requires_grad_(True), be.detach().clone().requires_grad_(True)
     c = F.conv2d(xr, wr, None, stride=stride, padding=dil, dilation=dil, groups=C)
     if dtype == torch.bfloat16:
-        c = c.to(dtype).float() + (c - c.detach())
+        c = c + (c.to(dtype).float() - c).detach()
     ref = F.silu(F.batch_norm(c, None, None, gr, ber, training=True))
     check("dw fwd", y, ref, dtype)
     go = nhwc(_rand(*y.shape, seed=7), dtype)
@@ -369,3 +369,17 @@ def test_linear_dropout_epilogue(ops, dtype):
     (gx,) = torch.autograd.grad(y, [x], torch.ones_like(y))
     gref = ((mask.float() / 0.75).to(dtype).float() @ w.detach().to(dtype).float())
     check("dropout epilogue dx", gx, gref, dtype, scale=3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,Ho,Wo", [(1, 1, 2, 2), (2, 2, 1, 1), (5, 5, 6, 6), (6, 6, 5, 5), (2, 3, 2, 4), (7, 9, 8, 10), (10, 10, 5, 7), (4, 4, 9, 13)])
+def test_resize_bilinear(ops, dtype, H, W, Ho, Wo):
+    x = nhwc(_rand(2, 16, H, W, seed=1), dtype).requires_grad_(True)
+    y = ops.resize_bilinear(x, Ho, Wo)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    check("resize fwd", y, ref, dtype)
+    go = nhwc(_rand(2, 16, Ho, Wo, seed=2), dtype)
+    (g,) = torch.autograd.grad(y, [x], go)
+    (r,) = torch.autograd.grad(ref, [xr], go.float())
+    check("resize bwd", g, r, dtype, scale=2)

@@ -19,7 +19,8 @@ from util import l2_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = [("mobilevit_xxs_32_b8", "xx_small", 8, 32), ("mobilevit_s_128_b2", "small", 2, 128), ("mobilevit_s_256_b2", "small", 2, 256)]
+CASES = [("mobilevit_xxs_32_b8", "xx_small", 8, 32), ("mobilevit_s_128_b2", "small", 2, 128), ("mobilevit_s_256_b2", "small", 2, 256),
+         ("mobilevit_s_160_b2", "small", 2, 160)]
 
 
 def _build(mode, dtype):
@@ -126,11 +127,15 @@ def test_rectangular_and_batch1():
         assert l2_err(got, ref) < 1e-4, shape
 
 
-def test_odd_patch_grid_is_rejected_loudly():
-    """160x160 -> layer_5 sees a 5x5 map: the reference bilinearly resizes to 6x6 (mobilevit_block.py:191-200).  That branch
-    has no HIP kernel yet; it must raise, never silently compute something else."""
-    from oracle.weights import seeded_input
+def test_unsupported_variants_fail_loudly():
+    """no silent fallbacks: configurations without a HIP kernel raise instead of computing something else."""
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
 
-    model, _ = _build("xx_small", torch.float32)
     with pytest.raises(NotImplementedError):
-        model(seeded_input((1, 3, 160, 160), seed=3).cuda())
+        cvnets_amd.MobileViT(default_opts(**{"model.activation.name": "relu"}))
+    with pytest.raises(NotImplementedError):
+        cvnets_amd.MobileViT(default_opts(**{"model.normalization.name": "group_norm"}))
+    m = cvnets_amd.MultiHeadAttention(64, 4).cuda()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 8, 64, device="cuda"), x_kv=torch.zeros(2, 8, 64, device="cuda"))

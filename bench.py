@@ -54,7 +54,7 @@ def cpu_baseline(args):
     from oracle.weights import seeded_input, seeded_labels, seeded_state_dict
     import cvnets_amd
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # PyTorch's CPU conv/GEMM stop scaling (and regress) past ~32 threads at this size
     torch.set_num_threads(cores)
     m = cvnets_amd.build_mobilevit(args.mode)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}

@@ -232,27 +232,39 @@ __global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                        const T* __restrict__ residual, T* __restrict__ y, size_t rows, int C) {
+  // thread = fixed 8-channel group (coefficients live in registers), row lanes walk the rows
   const int cgs = C / 8;
-  const size_t total = rows * cgs;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % cgs) * 8;
-    float f[8];
-    v8_unpack(v8_load<T>(x + idx * 8), f);
-    const float4 sa = *reinterpret_cast<const float4*>(scale + c0), sb = *reinterpret_cast<const float4*>(scale + c0 + 4);
-    const float4 ha = *reinterpret_cast<const float4*>(shift + c0), hb = *reinterpret_cast<const float4*>(shift + c0 + 4);
-    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+  const int RL = 256 / cgs;
+  const int ci = threadIdx.x % cgs, rl = threadIdx.x / cgs;
+  if (rl >= RL) return;
+  float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = act_fwd(f[j] * sc[j] + sh[j], act);
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[ci * 8 + j]; sh[j] = shift[ci * 8 + j]; }
+  const size_t step = (size_t)gridDim.x * RL;
+  for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += 2 * step) {
+    const size_t r2 = r + step;
+    const bool two = r2 < rows;
+    const size_t o1 = r * C + ci * 8, o2 = r2 * C + ci * 8;
+    V8<T> v1 = v8_load<T>(x + o1), v2 = two ? v8_load<T>(x + o2) : v8_zero<T>();
+    V8<T> q1 = v8_zero<T>(), q2 = v8_zero<T>();
     if (residual) {
-      float rf[8];
-      v8_unpack(v8_load<T>(residual + idx * 8), rf);
+      q1 = v8_load<T>(residual + o1);
+      if (two) q2 = v8_load<T>(residual + o2);
+    }
+    float f[8], g[8], rf[8], rg[8];
+    v8_unpack(v1, f); v8_unpack(v2, g); v8_unpack(q1, rf); v8_unpack(q2, rg);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] += rf[j];
+    for (int j = 0; j < 8; ++j) {
+      f[j] = act_fwd(f[j] * sc[j] + sh[j], act) + rf[j];
+      g[j] = act_fwd(g[j] * sc[j] + sh[j], act) + rg[j];
     }
     V8<T> o;
     v8_pack(f, o);
-    v8_store<T>(y + idx * 8, o);
+    v8_store<T>(y + o1, o);
+    if (two) {
+      v8_pack(g, o);
+      v8_store<T>(y + o2, o);
+    }
   }
 }
 
@@ -300,22 +312,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ cb, const float* __restrict__ cc, T* __restrict__ dx,
                                                            size_t rows, int C) {
   const int cgs = C / 8;
-  const size_t total = rows * cgs;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % cgs) * 8;
-    float xf[8], df[8], o[8];
-    v8_unpack(v8_load<T>(x + idx * 8), xf);
-    v8_unpack(v8_load<T>(dout + idx * 8), df);
+  const int RL = 256 / cgs;
+  const int ci = threadIdx.x % cgs, rl = threadIdx.x / cgs;
+  if (rl >= RL) return;
+  float sc[8], sh[8], a[8], b[8], c_[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = ci * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; a[j] = ca[c]; b[j] = cb[c]; c_[j] = cc[c];
+  }
+  const size_t step = (size_t)gridDim.x * RL;
+  for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += 2 * step) {
+    const size_t r2 = r + step;
+    const bool two = r2 < rows;
+    const size_t o1 = r * C + ci * 8, o2 = r2 * C + ci * 8;
+    V8<T> x1 = v8_load<T>(x + o1), d1 = v8_load<T>(dout + o1);
+    V8<T> x2 = two ? v8_load<T>(x + o2) : v8_zero<T>(), d2 = two ? v8_load<T>(dout + o2) : v8_zero<T>();
+    float xf[8], df[8], xg[8], dg[8], o[8], p[8];
+    v8_unpack(x1, xf); v8_unpack(d1, df); v8_unpack(x2, xg); v8_unpack(d2, dg);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = c0 + j;
-      float z = xf[j] * scale[c] + shift[c];
-      float dz = df[j] * act_grad(z, act);
-      o[j] = ca[c] * dz + cb[c] * xf[j] + cc[c];
+      o[j] = a[j] * (df[j] * act_grad(xf[j] * sc[j] + sh[j], act)) + b[j] * xf[j] + c_[j];
+      p[j] = a[j] * (dg[j] * act_grad(xg[j] * sc[j] + sh[j], act)) + b[j] * xg[j] + c_[j];
     }
     V8<T> ov;
     v8_pack(o, ov);
-    v8_store<T>(dx + idx * 8, ov);
+    v8_store<T>(dx + o1, ov);
+    if (two) {
+      v8_pack(p, ov);
+      v8_store<T>(dx + o2, ov);
+    }
   }
 }
 
@@ -569,9 +595,9 @@ extern "C" int cvh_bn_eval_coeff(const float* gamma, const float* beta, const fl
 }
 extern "C" int cvh_bn_apply(int dtype, const void* x, const float* scale, const float* shift, int act, const void* residual, void* y,
                             long long rows, int C, void* stream) {
-  if (C % 8) return -2;
-  size_t total = (size_t)rows * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, act, (const T*)residual, (T*)y, (size_t)rows, C);)
+  if (C % 8 || C > 2048 || C <= 0) return -2;
+  size_t total = ((size_t)rows + (size_t)(256 / (C / 8)) * 2 - 1) / ((size_t)(256 / (C / 8)) * 2);  // blocks: RL rows x 2 per pass
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total, 1)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, act, (const T*)residual, (T*)y, (size_t)rows, C);)
   CVH_CHECK_LAUNCH();
   return 0;
 }
@@ -592,9 +618,9 @@ extern "C" int cvh_bn_bwd_finalize(const float* part, int R, int C, double count
 }
 extern "C" int cvh_bn_bwd_apply(int dtype, const void* x, const void* dout, const float* scale, const float* shift, int act, const float* ca,
                                 const float* cb, const float* cc, void* dx, long long rows, int C, void* stream) {
-  if (C % 8) return -2;
-  size_t total = (size_t)rows * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dout, scale, shift, act, ca, cb, cc, (T*)dx, (size_t)rows, C);)
+  if (C % 8 || C > 2048 || C <= 0) return -2;
+  size_t total = ((size_t)rows + (size_t)(256 / (C / 8)) * 2 - 1) / ((size_t)(256 / (C / 8)) * 2);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(total, 1)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dout, scale, shift, act, ca, cb, cc, (T*)dx, (size_t)rows, C);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

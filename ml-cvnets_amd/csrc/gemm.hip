@@ -34,25 +34,41 @@ struct ConvGemmParams {
   int m_tiles;
 };
 
-template <typename T, int WM, int WN, int NF, int BK>
+// staging-group decomposition of the NF accumulator fragments of a wave: groups of 4 / 2 / 1 fragments so that the
+// number of 8-wide column chunks per staged row (16 / 8 / 4) divides the wave size
+template <int NF> struct StageGroups;
+template <> struct StageGroups<1> { static constexpr int n = 1; static constexpr int start[2] = {0, 0}; static constexpr int width[2] = {1, 0}; };
+template <> struct StageGroups<2> { static constexpr int n = 1; static constexpr int start[2] = {0, 0}; static constexpr int width[2] = {2, 0}; };
+template <> struct StageGroups<3> { static constexpr int n = 2; static constexpr int start[2] = {0, 2}; static constexpr int width[2] = {2, 1}; };
+template <> struct StageGroups<4> { static constexpr int n = 1; static constexpr int start[2] = {0, 0}; static constexpr int width[2] = {4, 0}; };
+template <> struct StageGroups<5> { static constexpr int n = 2; static constexpr int start[2] = {0, 4}; static constexpr int width[2] = {4, 1}; };
+
+template <typename T, int NF> constexpr int stage_pitch() { return (NF >= 4 ? 128 : (NF >= 2 ? 64 : 32)) + 16 / (int)sizeof(T); }
+
+// Workgroup = 4 waves stacked along M (BM = 128 rows), each wave owns a 32 x (32*NF) output strip.
+template <typename T, int NF, int BK>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
-  constexpr int BM = 32 * WM;
-  constexpr int BN = 32 * NF * WN;
+  constexpr int BM = 128;
+  constexpr int BN = 32 * NF;
   constexpr int CPR = BK / 8;
   constexpr int PITCH = lds_pitch<T>(BK);
   constexpr int A_IT = (BM * CPR + 255) / 256;
   constexpr int B_IT = (BN * CPR + 255) / 256;
+  constexpr int SP = stage_pitch<T, NF>();
+  constexpr int TILE_ELEMS = (BM + BN) * PITCH;
+  constexpr int STAGE_ELEMS = 4 * 32 * SP;
+  constexpr int MAIN_ELEMS = TILE_ELEMS > STAGE_ELEMS ? TILE_ELEMS : STAGE_ELEMS;
+  using SG = StageGroups<NF>;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* As = reinterpret_cast<T*>(smem_raw);
   T* Bs = As + BM * PITCH;
-  float* red = reinterpret_cast<float*>(Bs + BN * PITCH);  // [WM][2][BN] column partial sums
+  float* red = reinterpret_cast<float*>(As + MAIN_ELEMS);  // [2][BN] column sums (sum, sumsq), LDS atomics
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wave_m = wave / WN;
-  const int wave_n = wave % WN;
+  T* stg = As + wave * (32 * SP);  // per-wave output staging, aliases the operand tiles after the K loop
   const int n0 = blockIdx.y * BN;
   const int Cin = p.C1 + p.C2;
   const T* __restrict__ src1 = reinterpret_cast<const T*>(p.src1);
@@ -62,11 +78,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
 
   const int ccol = tid % CPR;  // this thread's 8-wide K chunk column inside a tile row (same for all its chunks)
   const bool pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
+  const bool want_stats = p.stats_part != nullptr;
 
-  // running column statistics (for BatchNorm) across all M tiles of this block
-  float cs1[NF], cs2[NF];
+  // running column statistics (BatchNorm) of this lane's 8-column chunk(s), across all M tiles of this block
+  float cs1[2][8], cs2[2][8];
 #pragma unroll
-  for (int f = 0; f < NF; ++f) cs1[f] = cs2[f] = 0.f;
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs1[g][j] = cs2[g][j] = 0.f;
+  if (want_stats) {
+    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+  }
 
   unsigned long long seed = 0;
   if (p.drop_p > 0.f) seed = *p.seed;
@@ -149,72 +171,104 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
 
     load_tiles(0);
     for (int k0 = 0; k0 < p.Ktot; k0 += BK) {
-      __syncthreads();  // previous tile fully consumed
+      __syncthreads();  // previous tile (or previous epilogue's staging) fully consumed
       store_tiles();
       __syncthreads();
       if (k0 + BK < p.Ktot) load_tiles(k0 + BK);  // prefetch next tile into registers under the MFMAs
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 16) {
-        Frag<T> a = lds_frag(As, PITCH, wave_m * 32, kk, lane);
+        Frag<T> a = lds_frag(As, PITCH, wave * 32, kk, lane);
         static_for<0, NF>([&](auto fi) {
           constexpr int f = decltype(fi)::value;
-          Frag<T> b = lds_frag(Bs, PITCH, wave_n * (32 * NF) + f * 32, kk, lane);
+          Frag<T> b = lds_frag(Bs, PITCH, f * 32, kk, lane);
           mma32(acc[f], a, b);
         });
       }
     }
 
-    // ---- epilogue ---- (compile-time frag index: keeps acc[] in registers for every NF)
-    static_for<0, NF>([&](auto fi) {
-      constexpr int f = decltype(fi)::value;
-      const int n = n0 + wave_n * (32 * NF) + f * 32 + (lane & 31);
-      const bool nok = n < p.N;
-      const float bias = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+    // ---- epilogue: accumulators -> (bias) -> per-wave LDS staging -> coalesced 16 B/lane rows with the fused
+    //      activation / act-grad / dropout / residual / BatchNorm statistics ----
+    __syncthreads();  // every wave is done reading As/Bs, which the staging area aliases
+    static_for<0, SG::n>([&](auto gi) {
+      constexpr int g = decltype(gi)::value;
+      constexpr int F0 = SG::start[g], GW = SG::width[g];
+      constexpr int CH = GW * 4;        // 8-wide chunks per staged row: 16 / 8 / 4
+      constexpr int RPP = 64 / CH;      // rows per pass
+      static_for<0, GW>([&](auto fi) {
+        constexpr int fl = decltype(fi)::value;
+        constexpr int f = F0 + fl;
+        const int n = n0 + f * 32 + (lane & 31);
+        const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave_m * 32 + acc_row(r, lane);
-        if (nok && m < p.M) {
-          const size_t o = (size_t)m * p.N + n;
-          float v = acc[f][r] + bias;
-          if (p.save_pre) reinterpret_cast<T*>(p.save_pre)[o] = from_f<T>(v);
-          v = act_fwd(v, p.act);
-          if (p.actgrad_aux) v *= act_grad(to_f<T>(reinterpret_cast<const T*>(p.actgrad_aux)[o]), p.actgrad_act);
-          if (p.drop_p > 0.f) v *= dropout_scale(seed, p.stream_id, o, p.drop_p, inv_keep);
-          if (p.residual) v += to_f<T>(reinterpret_cast<const T*>(p.residual)[o]);
-          T tv = from_f<T>(v);
-          out[o] = tv;
-          float vr = to_f<T>(tv);
-          cs1[f] += vr;
-          cs2[f] += vr * vr;
+        for (int r = 0; r < 16; ++r) stg[acc_row(r, lane) * SP + fl * 32 + (lane & 31)] = from_f<T>(acc[f][r] + bias);
+      });
+      __syncthreads();
+      const int ch = lane % CH;
+      const int n = n0 + F0 * 32 + ch * 8;
+      if (n < p.N) {
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+          const int row = pass * RPP + lane / CH;
+          const int m = m0 + wave * 32 + row;
+          if (m < p.M) {
+            const size_t o = (size_t)m * p.N + n;
+            V8<T> pv = v8_load<T>(stg + row * SP + ch * 8);
+            if (p.save_pre) v8_store<T>(reinterpret_cast<T*>(p.save_pre) + o, pv);
+            float v[8];
+            v8_unpack(pv, v);
+            if (p.act != CVH_ACT_NONE) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], p.act);
+            }
+            if (p.actgrad_aux) {
+              float a[8];
+              v8_unpack(v8_load<T>(reinterpret_cast<const T*>(p.actgrad_aux) + o), a);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= act_grad(a[j], p.actgrad_act);
+            }
+            if (p.drop_p > 0.f) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(seed, p.stream_id, o + j, p.drop_p, inv_keep);
+            }
+            if (p.residual) {
+              float rr[8];
+              v8_unpack(v8_load<T>(reinterpret_cast<const T*>(p.residual) + o), rr);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            }
+            V8<T> ov;
+            v8_pack(v, ov);
+            v8_store<T>(out + o, ov);
+            if (want_stats) {
+              float vr[8];
+              v8_unpack(ov, vr);  // statistics of the values as stored
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { cs1[g][j] += vr[j]; cs2[g][j] += vr[j] * vr[j]; }
+            }
+          }
         }
       }
+      __syncthreads();  // staging consumed before the next group / next tile overwrites it
     });
   }
 
-  if (p.stats_part) {
-    // combine the two half-waves (same column, different rows), then the WM waves stacked along M
-    static_for<0, NF>([&](auto fi) {
-      constexpr int f = decltype(fi)::value;
-      float s1 = cs1[f] + __shfl_xor(cs1[f], 32, 64);
-      float s2 = cs2[f] + __shfl_xor(cs2[f], 32, 64);
-      if (lane < 32) {
-        int col = wave_n * (32 * NF) + f * 32 + lane;
-        red[(wave_m * 2 + 0) * BN + col] = s1;
-        red[(wave_m * 2 + 1) * BN + col] = s2;
+  if (want_stats) {
+    static_for<0, SG::n>([&](auto gi) {
+      constexpr int g = decltype(gi)::value;
+      constexpr int CH = SG::width[g] * 4;
+      const int col = SG::start[g] * 32 + (lane % CH) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&red[col + j], cs1[g][j]);
+        atomicAdd(&red[BN + col + j], cs2[g][j]);
       }
     });
     __syncthreads();
     for (int col = tid; col < BN; col += 256) {
       int n = n0 + col;
       if (n < p.N) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          s1 += red[(w * 2 + 0) * BN + col];
-          s2 += red[(w * 2 + 1) * BN + col];
-        }
-        p.stats_part[(size_t)blockIdx.x * 2 * p.N + n] = s1;
-        p.stats_part[(size_t)blockIdx.x * 2 * p.N + p.N + n] = s2;
+        p.stats_part[(size_t)blockIdx.x * 2 * p.N + n] = red[col];
+        p.stats_part[(size_t)blockIdx.x * 2 * p.N + p.N + n] = red[BN + col];
       }
     }
   }
@@ -368,39 +422,48 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 // =============================================================================================
 // host-side dispatch
 // =============================================================================================
-template <typename T, int WM, int WN, int NF, int BK>
+template <typename T, int NF, int BK>
 static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
-  constexpr int BM = 32 * WM, BN = 32 * NF * WN;
+  constexpr int BM = 128, BN = 32 * NF;
   ConvGemmParams p = p0;
   p.m_tiles = (p.M + BM - 1) / BM;
   const int n_tiles = (p.N + BN - 1) / BN;
   int gx = p.m_tiles < 2048 ? p.m_tiles : 2048;
   dim3 grid(gx, n_tiles);
-  size_t smem = (size_t)(BM + BN) * lds_pitch<T>(BK) * sizeof(T) + (size_t)WM * 2 * BN * sizeof(float);
-  hipLaunchKernelGGL((conv_gemm_kernel<T, WM, WN, NF, BK>), grid, dim3(256), smem, st, p);
+  constexpr int TILE_ELEMS = (BM + BN) * lds_pitch<T>(BK);
+  constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
+  constexpr int MAIN_ELEMS = TILE_ELEMS > STAGE_ELEMS ? TILE_ELEMS : STAGE_ELEMS;
+  size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)2 * BN * sizeof(float);
+  auto kern = conv_gemm_kernel<T, NF, BK>;
+  if (smem > 64 * 1024) {
+    static bool attr_set = false;  // one instantiation = one static
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   CVH_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T, int BK>
-static int dispatch_conv_gemm_nf(const ConvGemmParams& p, int nf, bool small_m, hipStream_t st) {
-  if (small_m && nf >= 4) return launch_conv_gemm<T, 2, 2, 4, BK>(p, st);  // BM = 64, BN = 256
+static int dispatch_conv_gemm_nf(const ConvGemmParams& p, int nf, hipStream_t st) {
   switch (nf) {
-    case 1: return launch_conv_gemm<T, 4, 1, 1, BK>(p, st);
-    case 2: return launch_conv_gemm<T, 4, 1, 2, BK>(p, st);
-    case 3: return launch_conv_gemm<T, 4, 1, 3, BK>(p, st);
-    case 4: return launch_conv_gemm<T, 4, 1, 4, BK>(p, st);
-    case 5: return launch_conv_gemm<T, 4, 1, 5, BK>(p, st);
-    case 6: return launch_conv_gemm<T, 4, 1, 6, BK>(p, st);
-    default: return launch_conv_gemm<T, 4, 1, 8, BK>(p, st);
+    case 1: return launch_conv_gemm<T, 1, BK>(p, st);
+    case 2: return launch_conv_gemm<T, 2, BK>(p, st);
+    case 3: return launch_conv_gemm<T, 3, BK>(p, st);
+    case 4: return launch_conv_gemm<T, 4, BK>(p, st);
+    default: return launch_conv_gemm<T, 5, BK>(p, st);
   }
 }
 
 // choose the N tiling: fewest padded columns, then fewest tiles
 static int choose_nf(int N) {
-  static const int cand[7] = {1, 2, 3, 4, 5, 6, 8};
-  int best = 8, best_cost = 1 << 30;
-  for (int i = 0; i < 7; ++i) {
+  static const int cand[5] = {1, 2, 3, 4, 5};
+  int best = 4, best_cost = 1 << 30;
+  for (int i = 0; i < 5; ++i) {
     int bn = 32 * cand[i];
     int tiles = (N + bn - 1) / bn;
     int cost = tiles * bn * 16 + tiles;  // padded width dominates, tile count breaks ties
@@ -411,10 +474,8 @@ static int choose_nf(int N) {
 
 extern "C" int cvh_conv_gemm_grid_rows(int M, int N) {
   // number of stats-partial rows conv_gemm writes for an (M, N) problem (== gridDim.x)
-  int nf = choose_nf(N);
-  bool small_m = (M <= 16384) && nf >= 4;
-  int bm = small_m ? 64 : 128;
-  int mt = (M + bm - 1) / bm;
+  (void)N;
+  int mt = (M + 127) / 128;
   return mt < 2048 ? mt : 2048;
 }
 
@@ -423,7 +484,7 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
                              const float* bias, int act, void* save_pre, const void* actgrad_aux, int actgrad_act,
                              const void* residual, float drop_p, const unsigned long long* seed, unsigned int stream_id,
                              float* stats_part, void* stream) {
-  if ((C1 % 8) != 0 || (C2 % 8) != 0 || C1 <= 0) return -2;
+  if ((C1 % 8) != 0 || (C2 % 8) != 0 || C1 <= 0 || (N % 8) != 0) return -2;
   if (src2 == nullptr && C2 != 0) return -2;
   ConvGemmParams p;
   p.src1 = src1; p.src2 = src2; p.C1 = C1; p.C2 = C2; p.wgt = wgt; p.out = out;
@@ -435,12 +496,11 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   if (p.M <= 0 || N <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int nf = choose_nf(N);
-  const bool small_m = (p.M <= 16384) && nf >= 4;
   const bool bk64 = p.Ktot >= 64;
   if (dtype == CVH_DT_BF16) {
-    return bk64 ? dispatch_conv_gemm_nf<bf16_t, 64>(p, nf, small_m, st) : dispatch_conv_gemm_nf<bf16_t, 32>(p, nf, small_m, st);
+    return bk64 ? dispatch_conv_gemm_nf<bf16_t, 64>(p, nf, st) : dispatch_conv_gemm_nf<bf16_t, 32>(p, nf, st);
   } else if (dtype == CVH_DT_F32) {
-    return dispatch_conv_gemm_nf<float, 32>(p, nf, small_m, st);
+    return dispatch_conv_gemm_nf<float, 32>(p, nf, st);
   }
   return -1;
 }

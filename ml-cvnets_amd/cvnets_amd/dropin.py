@@ -1,0 +1,56 @@
+"""Drop the HIP path into a model built by the REFERENCE (``cvnets.get_model(opts)``) without editing the reference tree.
+
+The reference resolves its layers by Python class identity.  Because every cvnets_amd class keeps the
+reference class's attribute tree and parameter names, swapping ``module.__class__`` in place is enough: parameters, buffers,
+``state_dict`` keys, optimizer param groups, EMA deep-copies and checkpoints are untouched; only ``forward`` changes.
+
+    import cvnets, cvnets_amd.dropin as dropin
+    model = cvnets.get_model(opts)            # reference builder, reference YAML
+    dropin.swap_to_hip(model)                 # -> forward/backward now run libcvnets_hip.so kernels
+    Trainer(opts, model, ...).run(...)        # engine/training_engine.py unmodified
+
+Layers with no HIP implementation are left as they are and reported, never silently approximated.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+from torch import nn
+
+from . import layers, models, modules
+
+# reference class name -> cvnets_amd class (matched by name AND by defining package to avoid swapping foreign classes)
+_BY_NAME = {
+    "Conv2d": layers.Conv2d,
+    "ConvLayer2d": layers.ConvLayer2d,
+    "BatchNorm2d": layers.BatchNorm2d,
+    "LayerNorm": layers.LayerNorm,
+    "LinearLayer": layers.LinearLayer,
+    "Dropout": layers.Dropout,
+    "GlobalPool": layers.GlobalPool,
+    "MultiHeadAttention": layers.MultiHeadAttention,
+    "InvertedResidual": modules.InvertedResidual,
+    "TransformerEncoder": modules.TransformerEncoder,
+    "MobileViTBlock": modules.MobileViTBlock,
+    "MobileViT": models.MobileViT,
+}
+
+
+def swap_to_hip(model: nn.Module, strict: bool = False) -> Tuple[Dict[str, int], List[str]]:
+    """Class-swap every module of a reference-built model that has a HIP mirror.  Returns (counts per class, names of
+    parameter-owning modules left untouched).  ``strict=True`` raises if any parameter-owning cvnets module is left."""
+    counts: Dict[str, int] = {}
+    left: List[str] = []
+    for name, m in model.named_modules():
+        cls = m.__class__
+        if cls.__module__.startswith("cvnets_amd"):
+            continue
+        target = _BY_NAME.get(cls.__name__)
+        if target is not None and cls.__module__.startswith("cvnets."):
+            m.__class__ = target
+            counts[cls.__name__] = counts.get(cls.__name__, 0) + 1
+        elif cls.__module__.startswith("cvnets.") and any(True for _ in m.parameters(recurse=False)):
+            left.append(f"{name}:{cls.__name__}")
+    if strict and left:
+        raise NotImplementedError("no HIP mirror for: " + ", ".join(left))
+    return counts, left

@@ -1,0 +1,85 @@
+"""CPU / gloo / world_size 2 test of the data-parallel gradient exchange (cvnets_amd/ddp.py): flat buckets, post-accumulate
+hooks, end-of-backward join and the explicit post-graph-replay path must all produce the mean gradient on every rank, and
+parameters/buffers must start identical (rank-0 broadcast)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, explicit, q):
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cvnets_amd.ddp import DistributedDataParallel, distributed_init
+
+    assert distributed_init("gloo", torch.device("cpu")) == rank
+    torch.manual_seed(100 + rank)  # different init per rank: the ctor broadcast must fix that
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.001, overlap=True)  # tiny cap -> several buckets
+    assert len(ddp.buckets) >= 3
+    w0 = [p.detach().clone() for p in net.parameters()]
+    gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
+    dist.all_gather(gathered, w0[0])
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    torch.manual_seed(7 + rank)
+    x = torch.randn(12, 16)
+    ddp.zero_grad()
+    if explicit:
+        ddp.hooks_enabled = False
+        ddp(x).square().mean().backward()
+        ddp.allreduce_flat()
+    else:
+        ddp(x).square().mean().backward()
+    got = [p.grad.clone() for p in net.parameters()]
+    # reference: gradients of the same replica on every rank's batch, averaged
+    ref = [torch.zeros_like(p) for p in net.parameters()]
+    for r in range(world):
+        torch.manual_seed(7 + r)
+        xr = torch.randn(12, 16)
+        net2 = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+        net2.load_state_dict({k: v for k, v in zip(net.state_dict().keys(), [t.clone() for t in net.state_dict().values()])})
+        for p2, w in zip(net2.parameters(), w0):
+            p2.data.copy_(w)
+        net2[1].reset_running_stats()
+        net2(xr).square().mean().backward()
+        for a, p2 in zip(ref, net2.parameters()):
+            a += p2.grad / world
+    err = max(float((a - b).abs().max()) for a, b in zip(got, ref))
+    # a second step must work too (bucket counters reset)
+    ddp.zero_grad()
+    ddp.hooks_enabled = not explicit
+    ddp(x).square().mean().backward()
+    if explicit:
+        ddp.allreduce_flat()
+    q.put((rank, err, all(p.grad.data_ptr() != 0 for p in net.parameters())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("explicit", [False, True])
+def test_ddp_gloo_world2(explicit):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, explicit, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    for rank, err, ok in res:
+        assert err < 1e-6 and ok, (rank, err)

@@ -1,0 +1,78 @@
+"""CPU test of the drop-in boundary: a model built by the REFERENCE's own builder can be class-swapped onto
+the HIP mirrors with an identical module tree / state_dict; the mirrors then refuse to run without a GPU (no silent CPU path).
+Needs /root/reference (authoring container); skipped where the reference tree is absent (GPU box)."""
+import argparse
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present on this machine")
+
+
+@pytest.fixture(scope="module")
+def ref_model():
+    sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import yaml
+        import cvnets
+        from options.utils import flatten_yaml_as_dict
+        parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+        opts = parser.parse_args([])
+        cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/classification/imagenet/mobilevit.yaml")))
+        for k, v in cfg.items():
+            if hasattr(opts, k):
+                setattr(opts, k, v)
+        setattr(opts, "dataset.category", "classification")
+        setattr(opts, "dev.device", "cpu")
+        yield cvnets.get_model(opts), opts
+    finally:
+        os.chdir(cwd)
+
+
+def test_class_swap_keeps_tree_and_state_dict(ref_model):
+    import cvnets_amd
+    from cvnets_amd import dropin
+
+    model, opts = ref_model
+    before = {k: (tuple(v.shape), v.dtype) for k, v in model.state_dict().items()}
+    names_before = [n for n, _ in model.named_modules()]
+    counts, left = dropin.swap_to_hip(model, strict=True)
+    assert left == []
+    assert counts["MobileViTBlock"] == 3 and counts["InvertedResidual"] == 7 and counts["TransformerEncoder"] == 9
+    assert counts["ConvLayer2d"] == 35 and counts["MultiHeadAttention"] == 9 and counts["MobileViT"] == 1
+    assert {k: (tuple(v.shape), v.dtype) for k, v in model.state_dict().items()} == before
+    assert [n for n, _ in model.named_modules()] == names_before
+    gold = json.load(open(os.path.join(REPO, "tests", "golden", "mobilevit_small_keys.json")))
+    assert {k: list(s) for k, (s, _) in before.items()} == gold
+    # our own builder produces the same tree from the same opts
+    ours = cvnets_amd.MobileViT(opts)
+    assert [n for n, _ in ours.named_modules()] == names_before
+    assert list(ours.state_dict().keys()) == list(before.keys())
+    # and the swapped model has no CPU path
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 64, 64))
+
+
+def test_reference_attribute_contract(ref_model):
+    """attributes other reference code reaches into exist on the mirrors."""
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+    m = cvnets_amd.MobileViT(default_opts())
+    blk = m.layer_3[1]
+    for attr in ("local_rep", "global_rep", "conv_proj", "fusion", "patch_h", "patch_w", "cnn_in_dim", "cnn_out_dim", "n_heads", "ffn_dim", "n_blocks"):
+        assert hasattr(blk, attr), attr
+    enc = blk.global_rep[0]
+    assert enc.pre_norm_mha[1].qkv_proj.weight.shape == (3 * 144, 144)
+    assert enc.pre_norm_ffn[1].weight.shape == (288, 144) and enc.pre_norm_ffn[4].weight.shape == (144, 288)
+    conv = m.conv_1
+    for attr in ("block", "in_channels", "out_channels", "stride", "groups", "kernel_size", "bias", "dilation"):
+        assert hasattr(conv, attr), attr
+    assert [n for n, _ in conv.block.named_children()] == ["conv", "norm", "act"]

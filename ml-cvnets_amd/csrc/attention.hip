@@ -9,7 +9,8 @@
 // NHWC feature map — so unfold/fold cost nothing.  ph = pw = 1, H = 1, W = n_w = S gives the plain
 // contiguous [B][S][d] case (ViT / CLIP / standalone MultiHeadAttention).
 //
-// One 64-lane wave = one work item (sequence, head, 32-row block); all tiles live in that wave's LDS.
+// One 64-lane wave = one (sequence, head, 32-row block); a workgroup is NW (1/2/4) waves working on consecutive blocks of
+// the SAME (sequence, head), which share the staged K/V (or Q/dO) tiles; per-wave tiles live in that wave's LDS slice.
 // Every kernel forms the TRANSPOSED scores S^T = K Q^T, so the MFMA accumulator holds keys along rows and
 // the query along lane&31: the softmax statistics (max / sum / lse / D) are per-lane scalars.
 #include "common.hpp"
@@ -63,9 +64,9 @@ template <typename T, int VEC> __device__ __forceinline__ void st_vec(T* p, cons
 // rowidx[r] < 0 marks an absent row (zero filled).
 template <typename T, int CP, int VEC>
 __device__ __forceinline__ void stage_rows(T* lds, int pitch, const T* g, int ld, int col0, const int* rowidx, int nrows, int c, float scale,
-                                           int lane) {
+                                           int tid, int nthreads) {
   constexpr int CH = CP / VEC;
-  for (int idx = lane; idx < nrows * CH; idx += 64) {
+  for (int idx = tid; idx < nrows * CH; idx += nthreads) {
     const int r = idx / CH, cc = (idx - r * CH) * VEC;
     float f[VEC];
 #pragma unroll
@@ -128,33 +129,51 @@ __device__ __forceinline__ bool key_visible(const AttnParams& p, int s, int key,
 }
 
 // =============================================================================================
+// shared-memory carving (dynamic LDS; every offset is a multiple of 16 B)
+// =============================================================================================
+template <typename T> __device__ __forceinline__ T* carve(char*& p, int elems) {
+  T* r = reinterpret_cast<T*>(p);
+  p += ((size_t)elems * sizeof(T) + 15) / 16 * 16;
+  return r;
+}
+static size_t carve_bytes(size_t elems, size_t esz) { return (elems * esz + 15) / 16 * 16; }
+
+// =============================================================================================
 // forward
 // =============================================================================================
-template <typename T, int CP, int VEC>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+template <typename T, int CP, int VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   constexpr int KB = 64;
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int PP = lds_pitch<T>(KB);
   constexpr int NFC = CP / 32;
-  __shared__ __attribute__((aligned(16))) T Qs[32 * PQ];
-  __shared__ __attribute__((aligned(16))) T Ks[KB * PQ];
-  __shared__ __attribute__((aligned(16))) T Vs[KB * PQ];
-  __shared__ __attribute__((aligned(16))) T Ps[32 * PP];
-  __shared__ int rq[32];
-  __shared__ int rk[KB];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* sp = smem_raw;
+  T* Ks = carve<T>(sp, KB * PQ);
+  T* Vs = carve<T>(sp, KB * PQ);
+  T* Qs_all = carve<T>(sp, NW * 32 * PQ);
+  T* Ps_all = carve<T>(sp, NW * 32 * PP);
+  int* rk = carve<int>(sp, p.S);       // row index of every key of this sequence
+  int* rq_all = carve<int>(sp, NW * 32);
 
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* Qs = Qs_all + wave * 32 * PQ;
+  T* Ps = Ps_all + wave * 32 * PP;
+  int* rq = rq_all + wave * 32;
   const int nqb = (p.S + 31) / 32;
-  const int qb = blockIdx.x % nqb;
-  const int head = (blockIdx.x / nqb) % p.h;
-  const int s = blockIdx.x / (nqb * p.h);
-  const int q0 = qb * 32;
+  const int nqg = (nqb + NW - 1) / NW;
+  const int qg = blockIdx.x % nqg;
+  const int head = (blockIdx.x / nqg) % p.h;
+  const int s = blockIdx.x / (nqg * p.h);
+  const int q0 = (qg * NW + wave) * 32;
+  const int q0_last = (qg * NW + NW - 1) * 32;
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const int ld = 3 * p.d;
 
+  for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
-  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane);
+  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane, 64);
 
   const int my_q = q0 + (lane & 31);
   float m_run = -1e30f, l_run = 0.f;
@@ -163,12 +182,20 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
   for (int f = 0; f < NFC; ++f) oacc[f] = acc_zero();
 
   for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
-    if (p.causal && kv0 > q0 + 31) break;  // every key of this tile is in the future of every query of the block
-    __syncthreads();
-    rk[lane] = (kv0 + lane < p.S) ? seq_row(p.map, s, kv0 + lane) : -1;
-    __syncthreads();
-    stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
-    stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
+    if (p.causal && kv0 > q0_last + 31) break;  // tile entirely in the future of every query of the workgroup
+    __syncthreads();                             // previous tile's K/V (and this wave's P) fully consumed
+    {
+      const int nk = min(KB, p.S - kv0);
+      // rows beyond the sequence are zero-filled through a negative index trick: stage_rows reads rowidx[r]
+      stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
+      stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
+      if (nk < KB) {  // zero the tail rows of a partial tile (V rows feed the MFMA k-dimension)
+        for (int idx = tid; idx < (KB - nk) * PQ; idx += 64 * NW) {
+          Ks[nk * PQ + idx] = from_f<T>(0.f);
+          Vs[nk * PQ + idx] = from_f<T>(0.f);
+        }
+      }
+    }
     __syncthreads();
 
     // S^T[key][q] = sum_c K[key][c] * Qs[q][c]
@@ -216,7 +243,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
     for (int f = 0; f < NFC; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[f][r] *= alpha;
-    __syncthreads();
+    __syncthreads();  // P visible (wave-local data, workgroup barrier keeps the control flow uniform)
     // O^T[c][q] += sum_key V[key][c] * P^T[key][q]
 #pragma unroll
     for (int kk = 0; kk < KB; kk += 16) {
@@ -256,52 +283,66 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
 // =============================================================================================
 // backward prep: D[s,h,n] = sum_c dO * O
 // =============================================================================================
-template <typename T>
+template <typename T, int VEC>
 __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, AttnParams p) {
   const size_t total = (size_t)p.nseq * p.h * p.S;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(idx % p.S);
-    const int head = (int)((idx / p.S) % p.h);
+    const int head = (int)(idx % p.h);           // heads fastest: neighbouring lanes read neighbouring columns of one row
+    const int n = (int)((idx / p.h) % p.S);
     const int s = (int)(idx / ((size_t)p.S * p.h));
     const size_t row = (size_t)seq_row(p.map, s, n);
     float acc = 0.f;
-    for (int cc = 0; cc < p.c; ++cc)
-      acc += to_f<T>(o[row * p.d + head * p.c + cc]) * to_f<T>(dout[row * p.d + head * p.c + cc]);
-    p.dsum[idx] = acc;
+    for (int cc = 0; cc < p.c; cc += VEC) {
+      float a[VEC], b[VEC];
+      ld_vec<T, VEC>(o + row * p.d + head * p.c + cc, a);
+      ld_vec<T, VEC>(dout + row * p.d + head * p.c + cc, b);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc += a[e] * b[e];
+    }
+    p.dsum[((size_t)s * p.h + head) * p.S + n] = acc;
   }
 }
 
 // =============================================================================================
-// backward dQ: one wave per (sequence, head, 32-query block), loops over key tiles
+// backward dQ: wave = (sequence, head, 32-query block); the NW waves of a workgroup share the K/V tiles
 // =============================================================================================
-template <typename T, int CP, int VEC>
-__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
+template <typename T, int CP, int VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int KB = 64;
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int PP = lds_pitch<T>(KB);
   constexpr int NFC = CP / 32;
-  __shared__ __attribute__((aligned(16))) T Qs[32 * PQ];
-  __shared__ __attribute__((aligned(16))) T dOs[32 * PQ];
-  __shared__ __attribute__((aligned(16))) T Ks[KB * PQ];
-  __shared__ __attribute__((aligned(16))) T Vs[KB * PQ];
-  __shared__ __attribute__((aligned(16))) T dSs[32 * PP];
-  __shared__ int rq[32];
-  __shared__ int rk[KB];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* sp = smem_raw;
+  T* Ks = carve<T>(sp, KB * PQ);
+  T* Vs = carve<T>(sp, KB * PQ);
+  T* Qs_all = carve<T>(sp, NW * 32 * PQ);
+  T* dOs_all = carve<T>(sp, NW * 32 * PQ);
+  T* dSs_all = carve<T>(sp, NW * 32 * PP);
+  int* rk = carve<int>(sp, p.S);
+  int* rq_all = carve<int>(sp, NW * 32);
 
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* Qs = Qs_all + wave * 32 * PQ;
+  T* dOs = dOs_all + wave * 32 * PQ;
+  T* dSs = dSs_all + wave * 32 * PP;
+  int* rq = rq_all + wave * 32;
   const int nqb = (p.S + 31) / 32;
-  const int qb = blockIdx.x % nqb;
-  const int head = (blockIdx.x / nqb) % p.h;
-  const int s = blockIdx.x / (nqb * p.h);
-  const int q0 = qb * 32;
+  const int nqg = (nqb + NW - 1) / NW;
+  const int qg = blockIdx.x % nqg;
+  const int head = (blockIdx.x / nqg) % p.h;
+  const int s = blockIdx.x / (nqg * p.h);
+  const int q0 = (qg * NW + wave) * 32;
+  const int q0_last = (qg * NW + NW - 1) * 32;
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const T* dout = reinterpret_cast<const T*>(p.dout);
   const int ld = 3 * p.d;
 
+  for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
-  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane);
-  stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq, 32, p.c, 1.0f, lane);
+  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane, 64);
+  stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq, 32, p.c, 1.0f, lane, 64);
 
   const int my_q = q0 + (lane & 31);
   const bool q_ok = my_q < p.S;
@@ -313,12 +354,19 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
   for (int f = 0; f < NFC; ++f) dqacc[f] = acc_zero();
 
   for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
-    if (p.causal && kv0 > q0 + 31) break;
+    if (p.causal && kv0 > q0_last + 31) break;
     __syncthreads();
-    rk[lane] = (kv0 + lane < p.S) ? seq_row(p.map, s, kv0 + lane) : -1;
-    __syncthreads();
-    stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
-    stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, KB, p.c, 1.0f, lane);
+    {
+      const int nk = min(KB, p.S - kv0);
+      stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
+      stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
+      if (nk < KB) {
+        for (int idx = tid; idx < (KB - nk) * PQ; idx += 64 * NW) {
+          Ks[nk * PQ + idx] = from_f<T>(0.f);
+          Vs[nk * PQ + idx] = from_f<T>(0.f);
+        }
+      }
+    }
     __syncthreads();
 
     f32x16_t sacc[KB / 32], dpacc[KB / 32];
@@ -387,49 +435,66 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // =============================================================================================
-// backward dK, dV: one wave per (sequence, head, 32-key block), loops over 32-query blocks
+// backward dK, dV: wave = (sequence, head, 32-key block); the NW waves of a workgroup share the Q/dO tiles
 // =============================================================================================
-template <typename T, int CP, int VEC>
-__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(AttnParams p) {
+template <typename T, int CP, int VEC, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int QB = 32;
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int PT = lds_pitch<T>(QB);
   constexpr int NFC = CP / 32;
-  __shared__ __attribute__((aligned(16))) T Ks[32 * PQ];
-  __shared__ __attribute__((aligned(16))) T Vs[32 * PQ];
-  __shared__ __attribute__((aligned(16))) T Qs[QB * PQ];
-  __shared__ __attribute__((aligned(16))) T dOs[QB * PQ];
-  __shared__ __attribute__((aligned(16))) T PTs[32 * PT];
-  __shared__ __attribute__((aligned(16))) T dSTs[32 * PT];
-  __shared__ int rq[QB];
-  __shared__ int rk[32];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* sp = smem_raw;
+  T* Qs = carve<T>(sp, QB * PQ);
+  T* dOs = carve<T>(sp, QB * PQ);
+  T* Ks_all = carve<T>(sp, NW * 32 * PQ);
+  T* Vs_all = carve<T>(sp, NW * 32 * PQ);
+  T* PTs_all = carve<T>(sp, NW * 32 * PT);
+  T* dSTs_all = carve<T>(sp, NW * 32 * PT);
+  int* rq = carve<int>(sp, p.S);       // row index of every query of this sequence
+  int* rk_all = carve<int>(sp, NW * 32);
 
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* Ks = Ks_all + wave * 32 * PQ;
+  T* Vs = Vs_all + wave * 32 * PQ;
+  T* PTs = PTs_all + wave * 32 * PT;
+  T* dSTs = dSTs_all + wave * 32 * PT;
+  int* rk = rk_all + wave * 32;
   const int nkb = (p.S + 31) / 32;
-  const int kb = blockIdx.x % nkb;
-  const int head = (blockIdx.x / nkb) % p.h;
-  const int s = blockIdx.x / (nkb * p.h);
-  const int k0 = kb * 32;
+  const int nkg = (nkb + NW - 1) / NW;
+  const int kg = blockIdx.x % nkg;
+  const int head = (blockIdx.x / nkg) % p.h;
+  const int s = blockIdx.x / (nkg * p.h);
+  const int k0 = (kg * NW + wave) * 32;
+  const int k0_first = kg * NW * 32;
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const T* dout = reinterpret_cast<const T*>(p.dout);
   const int ld = 3 * p.d;
 
+  for (int i = tid; i < p.S; i += 64 * NW) rq[i] = seq_row(p.map, s, i);
   if (lane < 32) rk[lane] = (k0 + lane < p.S) ? seq_row(p.map, s, k0 + lane) : -1;
   __syncthreads();
-  stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, 32, p.c, 1.0f, lane);
-  stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, 32, p.c, 1.0f, lane);
+  stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, 32, p.c, 1.0f, lane, 64);
+  stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, 32, p.c, 1.0f, lane, 64);
 
   f32x16_t dkacc[NFC], dvacc[NFC];
 #pragma unroll
   for (int f = 0; f < NFC; ++f) { dkacc[f] = acc_zero(); dvacc[f] = acc_zero(); }
 
   for (int qb0 = 0; qb0 < p.S; qb0 += QB) {
-    if (p.causal && qb0 + QB - 1 < k0) continue;  // all queries of this block precede all keys of ours
+    if (p.causal && qb0 + QB - 1 < k0_first) continue;  // all queries of this block precede every key of the workgroup
     __syncthreads();
-    if (lane < QB) rq[lane] = (qb0 + lane < p.S) ? seq_row(p.map, s, qb0 + lane) : -1;
-    __syncthreads();
-    stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, QB, p.c, p.scaling, lane);
-    stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq, QB, p.c, 1.0f, lane);
+    {
+      const int nq = min(QB, p.S - qb0);
+      stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq + qb0, nq, p.c, p.scaling, tid, 64 * NW);
+      stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq + qb0, nq, p.c, 1.0f, tid, 64 * NW);
+      if (nq < QB) {
+        for (int idx = tid; idx < (QB - nq) * PQ; idx += 64 * NW) {
+          Qs[nq * PQ + idx] = from_f<T>(0.f);
+          dOs[nq * PQ + idx] = from_f<T>(0.f);
+        }
+      }
+    }
     __syncthreads();
 
     const int my_q = qb0 + (lane & 31);
@@ -507,57 +572,83 @@ static AttnParams make_params(const void* qkv, void* out, const void* dout, void
   return p;
 }
 
-#define ATTN_DISPATCH(KERNEL, GRID)                                                                              \
-  do {                                                                                                           \
-    const int vec = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);                                                   \
-    const bool cp32 = c <= 32;                                                                                   \
-    if (dtype == CVH_DT_BF16) {                                                                                  \
-      if (cp32) { if (vec == 4) hipLaunchKernelGGL((KERNEL<bf16_t, 32, 4>), dim3(GRID), dim3(64), 0, st, p);     \
-                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<bf16_t, 32, 2>), dim3(GRID), dim3(64), 0, st, p); \
-                  else hipLaunchKernelGGL((KERNEL<bf16_t, 32, 1>), dim3(GRID), dim3(64), 0, st, p); }            \
-      else      { if (vec == 4) hipLaunchKernelGGL((KERNEL<bf16_t, 64, 4>), dim3(GRID), dim3(64), 0, st, p);     \
-                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<bf16_t, 64, 2>), dim3(GRID), dim3(64), 0, st, p); \
-                  else hipLaunchKernelGGL((KERNEL<bf16_t, 64, 1>), dim3(GRID), dim3(64), 0, st, p); }            \
-    } else if (dtype == CVH_DT_F32) {                                                                            \
-      if (cp32) { if (vec == 4) hipLaunchKernelGGL((KERNEL<float, 32, 4>), dim3(GRID), dim3(64), 0, st, p);      \
-                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<float, 32, 2>), dim3(GRID), dim3(64), 0, st, p);  \
-                  else hipLaunchKernelGGL((KERNEL<float, 32, 1>), dim3(GRID), dim3(64), 0, st, p); }             \
-      else      { if (vec == 4) hipLaunchKernelGGL((KERNEL<float, 64, 4>), dim3(GRID), dim3(64), 0, st, p);      \
-                  else if (vec == 2) hipLaunchKernelGGL((KERNEL<float, 64, 2>), dim3(GRID), dim3(64), 0, st, p);  \
-                  else hipLaunchKernelGGL((KERNEL<float, 64, 1>), dim3(GRID), dim3(64), 0, st, p); }             \
-    } else return -1;                                                                                            \
-  } while (0)
+enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
+
+template <typename T, int CP, int NW> static size_t attn_smem(int which, int S) {
+  const size_t PQ = lds_pitch<T>(CP), PP = lds_pitch<T>(64), PT = lds_pitch<T>(32), e = sizeof(T);
+  size_t b = carve_bytes(S, 4) + carve_bytes(NW * 32, 4);
+  if (which == K_FWD) b += 2 * carve_bytes(64 * PQ, e) + carve_bytes(NW * 32 * PQ, e) + carve_bytes(NW * 32 * PP, e);
+  else if (which == K_DQ) b += 2 * carve_bytes(64 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + carve_bytes(NW * 32 * PP, e);
+  else b += 2 * carve_bytes(32 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + 2 * carve_bytes(NW * 32 * PT, e);
+  return b;
+}
+
+template <typename T, int CP, int VEC, int NW>
+static int launch_attn(int which, const AttnParams& p, hipStream_t st) {
+  const size_t smem = attn_smem<T, CP, NW>(which, p.S);
+  if (smem > 160 * 1024) return -2;
+  const int nb = (p.S + 31) / 32;
+  const int grid = p.nseq * p.h * ((nb + NW - 1) / NW);
+  const void* fn = which == K_FWD ? reinterpret_cast<const void*>(attn_fwd_kernel<T, CP, VEC, NW>)
+                   : which == K_DQ ? reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, CP, VEC, NW>)
+                                   : reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, CP, VEC, NW>);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (which == K_FWD) hipLaunchKernelGGL((attn_fwd_kernel<T, CP, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  else if (which == K_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, CP, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, CP, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int CP, int VEC>
+static int dispatch_nw(int which, const AttnParams& p, hipStream_t st) {
+  const int nb = (p.S + 31) / 32;
+  if (nb >= 4) return launch_attn<T, CP, VEC, 4>(which, p, st);
+  if (nb >= 2) return launch_attn<T, CP, VEC, 2>(which, p, st);
+  return launch_attn<T, CP, VEC, 1>(which, p, st);
+}
+template <typename T, int CP>
+static int dispatch_vec(int which, const AttnParams& p, hipStream_t st) {
+  if (p.c % 4 == 0) return dispatch_nw<T, CP, 4>(which, p, st);
+  if (p.c % 2 == 0) return dispatch_nw<T, CP, 2>(which, p, st);
+  return dispatch_nw<T, CP, 1>(which, p, st);
+}
+static int dispatch_attn(int dtype, int which, const AttnParams& p, hipStream_t st) {
+  const bool cp32 = p.c <= 32;
+  if (dtype == CVH_DT_BF16) return cp32 ? dispatch_vec<bf16_t, 32>(which, p, st) : dispatch_vec<bf16_t, 64>(which, p, st);
+  if (dtype == CVH_DT_F32) return cp32 ? dispatch_vec<float, 32>(which, p, st) : dispatch_vec<float, 64>(which, p, st);
+  return -1;
+}
 
 extern "C" int cvh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, int nseq, int S, int h, int c,
                             int ph, int pw, int n_w, int H, int W, float scaling, int causal, void* stream) {
-  if (c > 64 || c <= 0 || S <= 0) return -2;
+  if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
   AttnParams p = make_params(qkv, out, nullptr, nullptr, lse, nullptr, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
-  hipStream_t st = (hipStream_t)stream;
-  const int grid = nseq * h * ((S + 31) / 32);
-  ATTN_DISPATCH(attn_fwd_kernel, grid);
-  CVH_CHECK_LAUNCH();
-  return 0;
+  return dispatch_attn(dtype, K_FWD, p, (hipStream_t)stream);
 }
 
 extern "C" int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
                             const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
                             int causal, void* stream) {
-  if (c > 64 || c <= 0 || S <= 0) return -2;
+  if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
   AttnParams p = make_params(qkv, nullptr, dout, dqkv, const_cast<float*>(lse), dsum, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
   hipStream_t st = (hipStream_t)stream;
   {
     size_t total = (size_t)nseq * h * S;
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
-    if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((attn_bwd_prep_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, p);
-    else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((attn_bwd_prep_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)out, (const float*)dout, p);
+    const int vec = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
+#define PREP(TT, VV) hipLaunchKernelGGL((attn_bwd_prep_kernel<TT, VV>), dim3(g), dim3(256), 0, st, (const TT*)out, (const TT*)dout, p)
+    if (dtype == CVH_DT_BF16) { if (vec == 4) PREP(bf16_t, 4); else if (vec == 2) PREP(bf16_t, 2); else PREP(bf16_t, 1); }
+    else if (dtype == CVH_DT_F32) { if (vec == 4) PREP(float, 4); else if (vec == 2) PREP(float, 2); else PREP(float, 1); }
     else return -1;
+#undef PREP
     CVH_CHECK_LAUNCH();
   }
-  const int grid = nseq * h * ((S + 31) / 32);
-  ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
-  CVH_CHECK_LAUNCH();
-  ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
-  CVH_CHECK_LAUNCH();
-  return 0;
+  int rc = dispatch_attn(dtype, K_DQ, p, st);
+  if (rc) return rc;
+  return dispatch_attn(dtype, K_DKV, p, st);
 }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const T* __restrict__
 static int dw_grid(size_t npix, int C) {
   const int RL = 256 / (C / 8);
   size_t g = (npix + (size_t)RL * 4 - 1) / ((size_t)RL * 4);
-  if (g > 2048) g = 2048;
+  if (g > 1024) g = 1024;  // fwd/bwd_x grid; also the number of BN-statistics partial rows
   if (g < 1) g = 1;
   return (int)g;
 }

@@ -159,18 +159,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
 
 // sum partial rows: part[R][W] -> out[W]  (f64 accumulation); block = 64 columns x 16 row lanes
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int R, int stride, int Wd, float* __restrict__ out, float scale) {
-  __shared__ double red[16][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+  __shared__ double red[64][16];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rl = threadIdx.x >> 4;
   double s = 0.0;
   if (col < Wd)
-    for (int r = rl; r < R; r += 16) s += (double)part[(size_t)r * stride + col];
-  red[rl][threadIdx.x & 63] = s;
+    for (int r = rl; r < R; r += 64) s += (double)part[(size_t)r * stride + col];
+  red[rl][threadIdx.x & 15] = s;
   __syncthreads();
   if (rl == 0 && col < Wd) {
     double t = 0.0;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x & 63];
+    for (int l = 0; l < 64; ++l) t += red[l][threadIdx.x & 15];
     out[col] = (float)(t * (double)scale);
   }
 }
@@ -180,22 +180,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[16][2][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+  __shared__ double red[64][2][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rl = threadIdx.x >> 4;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int r = rl; r < R; r += 16) {
+    for (int r = rl; r < R; r += 64) {
       a += (double)part[(size_t)r * 2 * C + c];
       b += (double)part[(size_t)r * 2 * C + C + c];
     }
-  red[rl][0][threadIdx.x & 63] = a;
-  red[rl][1][threadIdx.x & 63] = b;
+  red[rl][0][threadIdx.x & 15] = a;
+  red[rl][1][threadIdx.x & 15] = b;
   __syncthreads();
   if (rl == 0 && c < C) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) { s1 += red[l][0][threadIdx.x & 63]; s2 += red[l][1][threadIdx.x & 63]; }
+    for (int l = 0; l < 64; ++l) { s1 += red[l][0][threadIdx.x & 15]; s2 += red[l][1][threadIdx.x & 15]; }
     double mu = s1 / count;
     double var = s2 / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -274,22 +274,22 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                const float* __restrict__ mean, const float* __restrict__ invstd, int training,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ca,
                                                                float* __restrict__ cb, float* __restrict__ cc) {
-  __shared__ double red[16][2][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+  __shared__ double red[64][2][16];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rl = threadIdx.x >> 4;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int r = rl; r < R; r += 16) {
+    for (int r = rl; r < R; r += 64) {
       a += (double)part[(size_t)r * 2 * C + c];
       b += (double)part[(size_t)r * 2 * C + C + c];
     }
-  red[rl][0][threadIdx.x & 63] = a;
-  red[rl][1][threadIdx.x & 63] = b;
+  red[rl][0][threadIdx.x & 15] = a;
+  red[rl][1][threadIdx.x & 15] = b;
   __syncthreads();
   if (rl == 0 && c < C) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) { s1 += red[l][0][threadIdx.x & 63]; s2 += red[l][1][threadIdx.x & 63]; }
+    for (int l = 0; l < 64; ++l) { s1 += red[l][0][threadIdx.x & 15]; s2 += red[l][1][threadIdx.x & 15]; }
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     const double g = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
@@ -552,7 +552,7 @@ extern "C" int cvh_colreduce_rows(long long rows, int C) {
   if (C % 8 || C > 2048 || C <= 0) return -2;
   const int RL = 256 / (C / 8);
   long long g = (rows + (long long)RL * 8 - 1) / ((long long)RL * 8);
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -570,19 +570,19 @@ extern "C" int cvh_colsum(int dtype, const void* x, long long rows, int C, float
   DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part);)
   CVH_CHECK_LAUNCH();
   // the plain sums live in the first C entries of each 2C-wide partial row
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, g, 2 * C, C, out, scale);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, g, 2 * C, C, out, scale);
   CVH_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int cvh_sum_partials(const float* part, int R, int Wd, float* out, float scale, void* stream) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((Wd + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, R, Wd, Wd, out, scale);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((Wd + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, Wd, Wd, out, scale);
   CVH_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int cvh_bn_finalize(const float* part, int R, int C, double count, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                                void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   CVH_CHECK_LAUNCH();
   return 0;
@@ -611,7 +611,7 @@ extern "C" int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, con
 }
 extern "C" int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,
                                    int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, mean, invstd, training,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, mean, invstd, training,
                      dgamma, dbeta, ca, cb, cc);
   CVH_CHECK_LAUNCH();
   return 0;

@@ -428,7 +428,7 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   ConvGemmParams p = p0;
   p.m_tiles = (p.M + BM - 1) / BM;
   const int n_tiles = (p.N + BN - 1) / BN;
-  int gx = p.m_tiles < 2048 ? p.m_tiles : 2048;
+  int gx = p.m_tiles < 512 ? p.m_tiles : 512;
   dim3 grid(gx, n_tiles);
   constexpr int TILE_ELEMS = (BM + BN) * lds_pitch<T>(BK);
   constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
@@ -476,7 +476,7 @@ extern "C" int cvh_conv_gemm_grid_rows(int M, int N) {
   // number of stats-partial rows conv_gemm writes for an (M, N) problem (== gridDim.x)
   (void)N;
   int mt = (M + 127) / 128;
-  return mt < 2048 ? mt : 2048;
+  return mt < 512 ? mt : 512;
 }
 
 extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2, const void* wgt, void* out,

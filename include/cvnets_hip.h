@@ -69,12 +69,12 @@ int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, i
 /* Replaces nn.Conv2d(groups=C) in InvertedResidual (cvnets/modules/mobilenetv2.py:194-207). */
 int cvh_dwconv_fwd(int dtype, const void* x, const void* wp, void* y, int B, int H, int W, int Ho, int Wo, int C, int K,
                    int stride, int pad, int dil, float* stats_part, void* stream);
-int cvh_dwconv_rows(int B, int Ho, int Wo, int C); /* rows of stats_part written by cvh_dwconv_fwd */
+int cvh_dwconv_rows(int B, int Ho, int Wo, int C, int K, int stride, int pad, int dil); /* rows of stats_part written by cvh_dwconv_fwd */
 int cvh_dwconv_bwd_x(int dtype, const void* dy, const void* wp, void* dx, int B, int H, int W, int Ho, int Wo, int C, int K,
                      int stride, int pad, int dil, void* stream);
 int cvh_dwconv_bwd_w(int dtype, const void* x, const void* dy, float* part, int B, int H, int W, int Ho, int Wo, int C, int K,
                      int stride, int pad, int dil, void* stream);
-int cvh_dwconv_bwd_w_rows(int B, int Ho, int Wo, int C); /* rows of part[rows][C*K*K] */
+int cvh_dwconv_bwd_w_rows(int B, int Ho, int Wo, int C, int K, int stride, int pad, int dil); /* rows of part[rows][C*K*K] */
 
 /* ---- BatchNorm2d (train-mode batch statistics) + activation ------------------------------------- */
 /* Replaces nn.BatchNorm2d (cvnets/layers/normalization/batch_norm.py:14-49) followed by nn.SiLU, and the

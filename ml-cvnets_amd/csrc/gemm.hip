@@ -47,7 +47,7 @@ template <typename T, int NF> constexpr int stage_pitch() { return (NF >= 4 ? 12
 
 // Workgroup = 4 waves stacked along M (BM = 128 rows), each wave owns a 32 x (32*NF) output strip.
 template <typename T, int NF, int BK>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int BM = 128;
   constexpr int BN = 32 * NF;
   constexpr int CPR = BK / 8;
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
   if (p.drop_p > 0.f) seed = *p.seed;
   const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
-  for (int tile_m = blockIdx.x; tile_m < p.m_tiles; tile_m += gridDim.x) {
-    const int m0 = tile_m * BM;
+  // ---- software pipeline across M tiles: the A/B registers of tile t+1 are requested before tile t's epilogue ----
+  int a_row[A_IT];
+  int a_b[A_IT], a_h[A_IT], a_w[A_IT];
+  bool a_ok[A_IT];
+  V8<T> ra[A_IT], rb[B_IT];
 
-    // ---- per-chunk row decode (fixed over the K loop) ----
-    int a_row[A_IT];
-    int a_b[A_IT], a_h[A_IT], a_w[A_IT];
-    bool a_ok[A_IT];
+  auto decode_rows = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int q = tid + i * 256;
@@ -119,62 +119,66 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
         a_b[i] = b; a_h[i] = ho * p.stride - p.pad; a_w[i] = wo * p.stride - p.pad;
       }
     }
+  };
+  auto load_tiles = [&](int k0) {
+    const int k = k0 + ccol * 8;
+    const bool kok = k < p.Ktot;
+    int tap = 0, c = k;
+    if (!pointwise) { tap = k / Cin; c = k - tap * Cin; }
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const T* s = src1; int cs = p.C1; int cc = c;
+    if (c >= p.C1) { s = src2; cs = p.C2; cc = c - p.C1; }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      ra[i] = v8_zero<T>();
+      if (a_ok[i] && kok) {
+        if (pointwise) {
+          ra[i] = v8_load<T>(s + (size_t)a_w[i] * cs + cc);
+        } else {
+          int hi = a_h[i] + kh * p.dil, wi = a_w[i] + kw * p.dil;
+          if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
+            ra[i] = v8_load<T>(s + ((size_t)(a_b[i] * p.H + hi) * p.W + wi) * cs + cc);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int q = tid + i * 256;
+      int r = q / CPR;
+      int n = n0 + r;
+      rb[i] = v8_zero<T>();
+      if (q < BN * CPR && n < p.N && kok) rb[i] = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int q = tid + i * 256;
+      if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int q = tid + i * 256;
+      if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, rb[i]);
+    }
+  };
+
+  if ((int)blockIdx.x < p.m_tiles) {
+    decode_rows(blockIdx.x * BM);
+    load_tiles(0);
+  }
+  for (int tile_m = blockIdx.x; tile_m < p.m_tiles; tile_m += gridDim.x) {
+    const int m0 = tile_m * BM;
 
     f32x16_t acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = acc_zero();
 
-    V8<T> ra[A_IT], rb[B_IT];
-
-    auto load_tiles = [&](int k0) {
-      const int k = k0 + ccol * 8;
-      const bool kok = k < p.Ktot;
-      int tap = 0, c = k;
-      if (!pointwise) { tap = k / Cin; c = k - tap * Cin; }
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      const T* s = src1; int cs = p.C1; int cc = c;
-      if (c >= p.C1) { s = src2; cs = p.C2; cc = c - p.C1; }
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        ra[i] = v8_zero<T>();
-        if (a_ok[i] && kok) {
-          if (pointwise) {
-            ra[i] = v8_load<T>(s + (size_t)a_w[i] * cs + cc);
-          } else {
-            int hi = a_h[i] + kh * p.dil, wi = a_w[i] + kw * p.dil;
-            if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W)
-              ra[i] = v8_load<T>(s + ((size_t)(a_b[i] * p.H + hi) * p.W + wi) * cs + cc);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        int q = tid + i * 256;
-        int r = q / CPR;
-        int n = n0 + r;
-        rb[i] = v8_zero<T>();
-        if (q < BN * CPR && n < p.N && kok) rb[i] = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
-      }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        int q = tid + i * 256;
-        if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, ra[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        int q = tid + i * 256;
-        if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, rb[i]);
-      }
-    };
-
-    load_tiles(0);
     for (int k0 = 0; k0 < p.Ktot; k0 += BK) {
       __syncthreads();  // previous tile (or previous epilogue's staging) fully consumed
       store_tiles();
       __syncthreads();
-      if (k0 + BK < p.Ktot) load_tiles(k0 + BK);  // prefetch next tile into registers under the MFMAs
+      if (k0 + BK < p.Ktot) load_tiles(k0 + BK);  // prefetch next K tile into registers under the MFMAs
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 16) {
         Frag<T> a = lds_frag(As, PITCH, wave * 32, kk, lane);
@@ -183,6 +187,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
           Frag<T> b = lds_frag(Bs, PITCH, f * 32, kk, lane);
           mma32(acc[f], a, b);
         });
+      }
+    }
+    {  // request the first operand tiles of the NEXT M tile now: their HBM latency hides under this tile's epilogue
+      const int next = tile_m + gridDim.x;
+      if (next < p.m_tiles) {
+        decode_rows(next * BM);
+        load_tiles(0);
       }
     }
 

@@ -30,10 +30,10 @@ SIGNATURES = {
     "cvh_conv_gemm_grid_rows": [I, I],
     "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
     "cvh_dwconv_fwd": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
-    "cvh_dwconv_rows": [I, I, I, I],
+    "cvh_dwconv_rows": [I, I, I, I, I, I, I, I],
     "cvh_dwconv_bwd_x": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cvh_dwconv_bwd_w": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
-    "cvh_dwconv_bwd_w_rows": [I, I, I, I],
+    "cvh_dwconv_bwd_w_rows": [I, I, I, I, I, I, I, I],
     "cvh_colreduce_rows": [L, I],
     "cvh_bn_stats": [I, P, L, I, P, P],
     "cvh_bn_finalize": [P, I, I, D, P, P, P, P, F, F, P, P, P, P, P],

@@ -358,7 +358,7 @@ class DWConvBNAct(torch.autograd.Function):
         ctx.shapes = (B, C, H, W, Ho, Wo, K)
         part, R = None, 0
         if use_bn and training:
-            R = _lib.query("cvh_dwconv_rows", B, Ho, Wo, C)
+            R = _lib.query("cvh_dwconv_rows", B, Ho, Wo, C, K, stride, pad, dil)
             part = _f32(R * 2 * C, dev)
         _lib.call("cvh_dwconv_fwd", _dt(x), _p(x), _p(wp), _p(y), B, H, W, Ho, Wo, C, K, stride, pad, dil, _p(part), _stream())
         if not use_bn:
@@ -385,7 +385,7 @@ class DWConvBNAct(torch.autograd.Function):
             dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, C, training)
         else:
             dy = dout
-        R = _lib.query("cvh_dwconv_bwd_w_rows", B, Ho, Wo, C)
+        R = _lib.query("cvh_dwconv_bwd_w_rows", B, Ho, Wo, C, K, stride, pad, dil)
         part = _f32(R * C * K * K, dev)
         _lib.call("cvh_dwconv_bwd_w", _dt(x), _p(x), _p(dy), _p(part), B, H, W, Ho, Wo, C, K, stride, pad, dil, _stream())
         dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)

@@ -119,24 +119,40 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
     }
   }
   if (rl < RL) {
-    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
-      float xf[8];
-      v8_unpack(v8_load<T>(x + r * C + ci * 8), xf);
+    const size_t step = (size_t)gridDim.x * RL;
+    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += 2 * step) {  // two rows in flight per thread
+      const size_t r2 = r + step;
+      const bool two = r2 < rows;
+      V8<T> xa = v8_load<T>(x + r * C + ci * 8);
+      V8<T> xb = two ? v8_load<T>(x + r2 * C + ci * 8) : v8_zero<T>();
+      V8<T> da = v8_zero<T>(), db = v8_zero<T>();
+      if (MODE == 1) {
+        da = v8_load<T>(dout + r * C + ci * 8);
+        if (two) db = v8_load<T>(dout + r2 * C + ci * 8);
+      }
+      float xf[8], xg[8];
+      v8_unpack(xa, xf);
+      v8_unpack(xb, xg);
       if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += xf[j]; s2[j] += xf[j] * xf[j]; }
+        for (int j = 0; j < 8; ++j) { s1[j] += xf[j] + xg[j]; s2[j] += xf[j] * xf[j] + xg[j] * xg[j]; }
       } else if (MODE == 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s1[j] += xf[j];
+        for (int j = 0; j < 8; ++j) s1[j] += xf[j] + xg[j];
       } else {
-        float df[8];
-        v8_unpack(v8_load<T>(dout + r * C + ci * 8), df);
+        float df[8], dg[8];
+        v8_unpack(da, df);
+        v8_unpack(db, dg);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float z = xf[j] * sc[j] + sh[j];
-          float dz = df[j] * act_grad(z, act);
+          float dz = df[j] * act_grad(xf[j] * sc[j] + sh[j], act);
           s1[j] += dz;
           s2[j] += dz * (xf[j] - mu[j]) * is[j];
+          if (two) {
+            float dz2 = dg[j] * act_grad(xg[j] * sc[j] + sh[j], act);
+            s1[j] += dz2;
+            s2[j] += dz2 * (xg[j] - mu[j]) * is[j];
+          }
         }
       }
     }

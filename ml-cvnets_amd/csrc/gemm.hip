@@ -359,8 +359,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
   const int m_begin = blockIdx.y * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
 
-  V8<T> d0, d1, x0, x1;
-  auto load_stage = [&](int ms) {
+  // PF register stages in flight per thread (each = 2 rows of dY + 2 rows of A): the ring is indexed statically by unrolling
+  constexpr int PF = 4;
+  V8<T> rd0[PF], rd1[PF], rx0[PF], rx1[PF];
+  auto load_stage = [&](V8<T>& d0, V8<T>& d1, V8<T>& x0, V8<T>& x1, int ms) {
     d0 = d1 = x0 = x1 = v8_zero<T>();
     const int ma = ms + 2 * mp, mb = ma + 1;
     if (n_ok) {
@@ -392,23 +394,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     }
   };
 
-  if (m_begin < m_end) load_stage(m_begin);
-  for (int ms = m_begin; ms < m_end; ms += BMR) {
-    __syncthreads();
-    store_transposed_pair(Dt + (nc * 8) * PITCH + 2 * mp, PITCH, d0, d1);
-    store_transposed_pair(Xt + (nc * 8) * PITCH + 2 * mp, PITCH, x0, x1);
-    __syncthreads();
-    if (ms + BMR < m_end) load_stage(ms + BMR);
 #pragma unroll
-    for (int kk = 0; kk < BMR; kk += 16) {
-      Frag<T> a0 = lds_frag(Dt, PITCH, wave_n * 64, kk, lane);
-      Frag<T> a1 = lds_frag(Dt, PITCH, wave_n * 64 + 32, kk, lane);
-      Frag<T> b0 = lds_frag(Xt, PITCH, wave_k * 64, kk, lane);
-      Frag<T> b1 = lds_frag(Xt, PITCH, wave_k * 64 + 32, kk, lane);
-      mma32(acc[0][0], a0, b0);
-      mma32(acc[0][1], a0, b1);
-      mma32(acc[1][0], a1, b0);
-      mma32(acc[1][1], a1, b1);
+  for (int u = 0; u < PF; ++u)
+    if (m_begin + u * BMR < m_end) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], m_begin + u * BMR);
+  for (int ms0 = m_begin; ms0 < m_end; ms0 += PF * BMR) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int ms = ms0 + u * BMR;
+      if (ms < m_end) {  // uniform across the workgroup
+        __syncthreads();
+        store_transposed_pair(Dt + (nc * 8) * PITCH + 2 * mp, PITCH, rd0[u], rd1[u]);
+        store_transposed_pair(Xt + (nc * 8) * PITCH + 2 * mp, PITCH, rx0[u], rx1[u]);
+        __syncthreads();
+        if (ms + PF * BMR < m_end) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ms + PF * BMR);
+#pragma unroll
+        for (int kk = 0; kk < BMR; kk += 16) {
+          Frag<T> a0 = lds_frag(Dt, PITCH, wave_n * 64, kk, lane);
+          Frag<T> a1 = lds_frag(Dt, PITCH, wave_n * 64 + 32, kk, lane);
+          Frag<T> b0 = lds_frag(Xt, PITCH, wave_k * 64, kk, lane);
+          Frag<T> b1 = lds_frag(Xt, PITCH, wave_k * 64 + 32, kk, lane);
+          mma32(acc[0][0], a0, b0);
+          mma32(acc[0][1], a0, b1);
+          mma32(acc[1][0], a1, b0);
+          mma32(acc[1][1], a1, b1);
+        }
+      }
     }
   }
 
@@ -528,8 +538,8 @@ extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const vo
   const int n_tiles = (N + 127) / 128;
   p.k_tiles = (p.Ktot + 127) / 128;
   const int out_tiles = n_tiles * p.k_tiles;
-  // enough splits over M to fill the chip (~1024 workgroups), each at least 256 rows
-  int splits = (1024 + out_tiles - 1) / out_tiles;
+  // enough splits over M to put ~2 deep-prefetching workgroups on every CU (fewer splits = fewer fp32 atomics)
+  int splits = (512 + out_tiles - 1) / out_tiles;
   int max_splits = (p.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -117,9 +117,11 @@ def main():
     cvnets_amd.set_compute_dtype(dtype)
     torch.manual_seed(1234 + rank)
     model = cvnets_amd.build_mobilevit(args.mode).to(dev).train()
-    ddp = DistributedDataParallel(model, bucket_cap_mb=25.0, broadcast_buffers=False) if world > 1 else None
-    if ddp is not None:
-        ddp.hooks_enabled = False  # hipGraph replay does not run autograd hooks: buckets are reduced right after the replay
+    # gradients live in flat fp32 buckets (one zero-fill per step, one RCCL message per bucket); with world == 1 the wrapper
+    # only provides the flat storage.  Backward kernels add parameter gradients straight into those buffers.
+    ddp = DistributedDataParallel(model, bucket_cap_mb=25.0, broadcast_buffers=False)
+    ddp.hooks_enabled = False  # hipGraph replay does not run autograd hooks: buckets are reduced right after the replay
+    cvnets_amd.ops.set_inplace_param_grads(True)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = None
     if not args.no_optimizer:
@@ -129,11 +131,7 @@ def main():
     y = torch.randint(0, 1000, (args.batch,), device=dev)
 
     def zero_grads():
-        if ddp is not None:
-            ddp.zero_grad()
-        else:
-            for p in params:
-                p.grad = None
+        ddp.zero_grad()
 
     def fwd_bwd():
         logits = model(x)
@@ -149,14 +147,14 @@ def main():
         nonlocal static_loss
         if graph is not None:
             graph.replay()
-            if ddp is not None:
+            if world > 1:
                 ddp.allreduce_flat()
         else:
             zero_grads()
             static_loss = fwd_bwd()
-            if ddp is not None:
+            if world > 1:
                 ddp.allreduce_flat()
-        if opt is not None and (graph is None or ddp is not None):
+        if opt is not None and (graph is None or world > 1):
             opt.step()
 
     # eager warm-up (also creates every lazily-built tensor before capture)
@@ -175,18 +173,10 @@ def main():
     if use_graph:
         try:
             g = torch.cuda.CUDAGraph()
-            zero_grads()
-            if ddp is None:
-                for p in params:  # gradients must be static tensors across replays
-                    p.grad = torch.zeros_like(p)
             with torch.cuda.graph(g):
-                if ddp is not None:
-                    ddp.zero_grad()
-                else:
-                    for p in params:
-                        p.grad.zero_()
+                ddp.zero_grad()
                 static_loss = fwd_bwd()
-                if opt is not None and ddp is None:
+                if opt is not None and world == 1:
                     opt.step()
             graph = g
         except Exception as e:  # pragma: no cover - reported in the JSON line

@@ -41,6 +41,9 @@ int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H,
  * [Cout][KH*KW][pad8(Cin)];  mode 1: dX pack (transposed, taps flipped) [Cin][KH*KW][pad8(Cout)];
  * mode 2: depthwise [KH*KW][C].  Replaces autocast's per-call weight cast (engine/utils.py:19-36). */
 int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, int Cin, int KHW, int mode, void* stream);
+/* every conv / linear weight of a model packed by ONE launch: table = n_entries x {src ptr, dst element offset, Cout, Cin, KHW,
+ * mode, first global element} (int64, device memory), out = flat `dtype` buffer. */
+int cvh_weight_pack_multi(int dtype, const long long* table, int n_entries, long long total, void* out, void* stream);
 int cvh_cast_from_f32(int dtype, const float* in, void* out, long long n, void* stream);
 int cvh_cast_to_f32(int dtype, const void* in, float* out, long long n, void* stream);
 
@@ -91,13 +94,14 @@ int cvh_bn_apply(int dtype, const void* x, const float* scale, const float* shif
 int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int act, long long rows, int C, float* part, void* stream);
 int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,
-                        int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream);
+                        int training, int accumulate, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream);
 int cvh_bn_bwd_apply(int dtype, const void* x, const void* dout, const float* scale, const float* shift, int act, const float* ca,
                      const float* cb, const float* cc, void* dx, long long rows, int C, void* stream);
 
 /* ---- reductions / small ops --------------------------------------------------------------------- */
-int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, void* stream); /* bias grads */
-int cvh_sum_partials(const float* part, int R, int Wd, float* out, float scale, void* stream);
+/* `accumulate` != 0: results are ADDED to the destination (parameter gradients written straight into .grad buffers) */
+int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, int accumulate, void* stream); /* bias grads */
+int cvh_sum_partials(const float* part, int R, int stride, int Wd, float* out, float scale, int accumulate, void* stream);
 /* GlobalPool(mean) cvnets/layers/global_pool.py:60-71 */
 int cvh_pool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, void* stream);
 int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, void* stream);

@@ -82,6 +82,40 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// all weights of a model in ONE launch.  table[e] = {src ptr, dst element offset, Cout, Cin, KHW, mode, first global element}
+// (7 x int64 per entry, entries sorted by first element; table[n][6] = total).  Same three layouts as above.
+template <typename T>
+__global__ void weight_pack_multi_kernel(const long long* __restrict__ table, int n, long long total, T* __restrict__ out) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // last entry whose first element <= idx
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[(size_t)mid * 7 + 6] <= idx) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = table + (size_t)lo * 7;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    const long long li = idx - e[6];
+    const int Cout = (int)e[2], Cin = (int)e[3], KHW = (int)e[4], mode = (int)e[5];
+    const int Cp = (Cin + 7) / 8 * 8, Np = (Cout + 7) / 8 * 8;
+    float v = 0.f;
+    if (mode == 0) {
+      const int c = (int)(li % Cp);
+      const long long t = li / Cp;
+      const int tap = (int)(t % KHW), nn = (int)(t / KHW);
+      if (c < Cin) v = w[((size_t)nn * Cin + c) * KHW + tap];
+    } else if (mode == 1) {
+      const int nn = (int)(li % Np);
+      const long long t = li / Np;
+      const int tap = (int)(t % KHW), c = (int)(t / KHW);
+      if (nn < Cout) v = w[((size_t)nn * Cin + c) * KHW + (KHW - 1 - tap)];
+    } else {
+      const int c = (int)(li % Cout), tap = (int)(li / Cout);
+      v = w[(size_t)c * KHW + tap];
+    }
+    out[e[1] + li] = from_f<T>(v);
+  }
+}
+
 // f32 vector -> T (bias etc.), or T -> f32
 template <typename T>
 __global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
 }
 
 // sum partial rows: part[R][W] -> out[W]  (f64 accumulation); block = 64 columns x 16 row lanes
-__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int R, int stride, int Wd, float* __restrict__ out, float scale) {
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int R, int stride, int Wd, float* __restrict__ out, float scale, int accumulate) {
   __shared__ double red[64][16];
   const int col = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
@@ -187,7 +221,8 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restr
     double t = 0.0;
 #pragma unroll
     for (int l = 0; l < 64; ++l) t += red[l][threadIdx.x & 15];
-    out[col] = (float)(t * (double)scale);
+    const float r = (float)(t * (double)scale);
+    out[col] = accumulate ? out[col] + r : r;
   }
 }
 
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 // BatchNorm backward finalize: part[R][2][C] = (sum dz, sum dz*xhat)  ->  dgamma, dbeta and the per-channel
 // coefficients of  dx = ca*dz + cb*x + cc   (train mode; eval mode: ca = gamma*invstd, cb = cc = 0)
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, double count, const float* __restrict__ gamma,
-                                                               const float* __restrict__ mean, const float* __restrict__ invstd, int training,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd, int training, int accumulate,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ca,
                                                                float* __restrict__ cb, float* __restrict__ cc) {
   __shared__ double red[64][2][16];
@@ -306,8 +341,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int l = 0; l < 64; ++l) { s1 += red[l][0][threadIdx.x & 15]; s2 += red[l][1][threadIdx.x & 15]; }
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     const double g = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
     if (training) {
       ca[c] = (float)(g * is);
@@ -552,6 +587,12 @@ extern "C" int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, i
   CVH_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int cvh_weight_pack_multi(int dtype, const long long* table, int n_entries, long long total, void* out, void* stream) {
+  if (n_entries <= 0 || total <= 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((weight_pack_multi_kernel<T>), dim3(grid_for((size_t)total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, table, n_entries, total, (T*)out);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int cvh_cast_from_f32(int dtype, const float* in, void* out, long long n, void* stream) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((cast_from_f32_kernel<T>), dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, in, (T*)out, (size_t)n);)
   CVH_CHECK_LAUNCH();
@@ -580,18 +621,18 @@ extern "C" int cvh_bn_stats(int dtype, const void* x, long long rows, int C, flo
   CVH_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, void* stream) {
+extern "C" int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, int accumulate, void* stream) {
   int g = cvh_colreduce_rows(rows, C);
   if (g < 0) return g;
   DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part);)
   CVH_CHECK_LAUNCH();
   // the plain sums live in the first C entries of each 2C-wide partial row
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, g, 2 * C, C, out, scale);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, g, 2 * C, C, out, scale, accumulate);
   CVH_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int cvh_sum_partials(const float* part, int R, int Wd, float* out, float scale, void* stream) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((Wd + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, Wd, Wd, out, scale);
+extern "C" int cvh_sum_partials(const float* part, int R, int stride, int Wd, float* out, float scale, int accumulate, void* stream) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((Wd + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, stride, Wd, out, scale, accumulate);
   CVH_CHECK_LAUNCH();
   return 0;
 }
@@ -626,9 +667,9 @@ extern "C" int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, con
   return 0;
 }
 extern "C" int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,
-                                   int training, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream) {
+                                   int training, int accumulate, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, mean, invstd, training,
-                     dgamma, dbeta, ca, cb, cc);
+                     accumulate, dgamma, dbeta, ca, cb, cc);
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -24,6 +24,7 @@ SIGNATURES = {
     "cvh_nchw_to_nhwc": [I, P, P, I, I, I, I, I, P],
     "cvh_nhwc_to_nchw": [I, P, P, I, I, I, I, I, P],
     "cvh_weight_pack": [I, P, P, I, I, I, I, P],
+    "cvh_weight_pack_multi": [I, P, I, L, P, P],
     "cvh_cast_from_f32": [I, P, P, L, P],
     "cvh_cast_to_f32": [I, P, P, L, P],
     "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
@@ -40,10 +41,10 @@ SIGNATURES = {
     "cvh_bn_eval_coeff": [P, P, P, P, F, I, P, P, P, P, P],
     "cvh_bn_apply": [I, P, P, P, I, P, P, L, I, P],
     "cvh_bn_bwd_reduce": [I, P, P, P, P, P, P, I, L, I, P, P],
-    "cvh_bn_bwd_finalize": [P, I, I, D, P, P, P, I, P, P, P, P, P, P],
+    "cvh_bn_bwd_finalize": [P, I, I, D, P, P, P, I, I, P, P, P, P, P, P],
     "cvh_bn_bwd_apply": [I, P, P, P, P, I, P, P, P, P, L, I, P],
-    "cvh_colsum": [I, P, L, I, P, P, F, P],
-    "cvh_sum_partials": [P, I, I, P, F, P],
+    "cvh_colsum": [I, P, L, I, P, P, F, I, P],
+    "cvh_sum_partials": [P, I, I, I, P, F, I, P],
     "cvh_pool_fwd": [I, P, P, I, I, I, P],
     "cvh_pool_bwd": [I, P, P, I, I, I, P],
     "cvh_dropout": [I, P, P, L, F, P, U, P],

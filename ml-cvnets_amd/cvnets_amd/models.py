@@ -112,6 +112,7 @@ class MobileViT(nn.Module):
     def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
         if self.training:
             ops.advance_dropout_seed(x.device)
+            ops.pack_all(self)  # every conv / linear weight packed by one launch for this step
         x = ops.to_nhwc(x)
         x = self.conv_1(x)
         x = self.layer_1(x)

@@ -14,6 +14,7 @@ Tensor conventions
 from __future__ import annotations
 
 import itertools
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -164,8 +165,104 @@ def next_stream_id() -> int:
 # ------------------------------------------------------------------------------------------------
 # weight packing
 # ------------------------------------------------------------------------------------------------
+_PACKED = {}  # (data_ptr, mode, dtype) -> (packed view, parameter version it was packed from, weakref to the parameter)
+
+
+def _pack_numel(shape, mode: int) -> int:
+    Cout, Cin = shape[0], shape[1]
+    KHW = 1 if len(shape) == 2 else shape[2] * shape[3]
+    if mode == 0:
+        return Cout * KHW * pad8(Cin)
+    if mode == 1:
+        return Cin * KHW * pad8(Cout)
+    return KHW * Cout
+
+
+class PackPlan:
+    """All conv / linear weights of a module tree packed by ONE kernel launch per step (cvh_weight_pack_multi) into a flat
+    compute-dtype buffer; `pack_weight` then hands out views.  Replaces ~140 per-layer pack launches per training step."""
+
+    def __init__(self, module: torch.nn.Module, dtype: torch.dtype):
+        entries = []
+        for m in module.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                w = m.weight
+                if m.groups == 1:
+                    entries.append((w, 0))
+                    if m.stride[0] == 1:
+                        entries.append((w, 1))
+                elif m.groups == m.in_channels == m.out_channels:
+                    entries.append((w, 2))
+            elif hasattr(m, "weight") and isinstance(getattr(m, "weight", None), torch.nn.Parameter) and m.weight.dim() == 2 \
+                    and m.__class__.__name__ == "LinearLayer":
+                entries.append((m.weight, 0))
+                entries.append((m.weight, 1))
+        self.dtype = dtype
+        self.entries = [(w, mode) for w, mode in entries if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()]
+        self.ptrs = [w.data_ptr() for w, _ in self.entries]
+        dev = self.entries[0][0].device if self.entries else None
+        table, off, start = [], 0, 0
+        self.offsets = []
+        for w, mode in self.entries:
+            n = _pack_numel(w.shape, mode)
+            KHW = 1 if w.dim() == 2 else w.shape[2] * w.shape[3]
+            table.append([w.data_ptr(), off, w.shape[0], w.shape[1], KHW, mode, start])
+            self.offsets.append((off, n))
+            off += (n + 7) // 8 * 8
+            start += n
+        self.total = start
+        table.append([0, 0, 0, 0, 0, 0, start])
+        if self.entries:
+            self.table = torch.tensor(table, dtype=torch.int64, device=dev)
+            self.flat = torch.empty(max(off, 8), dtype=dtype, device=dev)
+
+    def valid(self) -> bool:
+        return all(w.data_ptr() == p for (w, _), p in zip(self.entries, self.ptrs))
+
+    def run(self) -> None:
+        if not self.entries:
+            return
+        _lib.call("cvh_weight_pack_multi", _dt(self.flat), _p(self.table), len(self.entries), self.total, _p(self.flat), _stream())
+        for (w, mode), (off, n) in zip(self.entries, self.offsets):
+            _PACKED[(w.data_ptr(), mode, self.dtype)] = (self.flat[off: off + n], w._version, weakref.ref(w))
+
+
+def pack_all(module: torch.nn.Module, dtype: Optional[torch.dtype] = None) -> None:
+    """Pack every weight under `module` for the coming step (call at the start of a training forward; it is captured into the
+    step's hipGraph, so replays re-pack the freshly updated parameters)."""
+    dtype = dtype or compute_dtype()
+    plan = module.__dict__.get("_cvh_pack_plan")
+    if plan is None or plan.dtype != dtype or not plan.valid():
+        plan = PackPlan(module, dtype)
+        module.__dict__["_cvh_pack_plan"] = plan
+    plan.run()
+
+
+_INPLACE_PARAM_GRADS = False
+
+
+def set_inplace_param_grads(flag: bool) -> None:
+    """When on, backward kernels ADD parameter gradients straight into existing ``param.grad`` buffers (zeroed by the caller,
+    e.g. one flat bucket) and hand autograd ``None`` — no per-parameter zero-fill / AccumulateGrad add kernels.  Autograd
+    post-accumulate hooks do not fire for those parameters (bench.py's hipGraph step reduces the flat buckets explicitly)."""
+    global _INPLACE_PARAM_GRADS
+    _INPLACE_PARAM_GRADS = bool(flag)
+
+
+def _grad_sink(param: Optional[torch.Tensor]):
+    if not _INPLACE_PARAM_GRADS or param is None:
+        return None
+    g = param.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+        return None
+    return g
+
+
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, mode: int) -> torch.Tensor:
     """mode 0: [Cout][KH*KW][pad8(Cin)] ; mode 1: [Cin][KH*KW][pad8(Cout)] (taps flipped) ; mode 2: depthwise [KH*KW][C]."""
+    hit = _PACKED.get((w.data_ptr(), mode, dtype))
+    if hit is not None and hit[1] == w._version and hit[2]() is w:
+        return hit[0]
     wf = w.detach()
     if wf.dtype != torch.float32 or not wf.is_contiguous():
         wf = wf.float().contiguous()  # plumbing (parameters are fp32 contiguous in practice)
@@ -210,12 +307,13 @@ def _act_backward(pre: torch.Tensor, dout: torch.Tensor, act: int, rows: int, C:
     return dx
 
 
-def _colsum(x2d: torch.Tensor, rows: int, C: int) -> torch.Tensor:
+def _colsum(x2d: torch.Tensor, rows: int, C: int, sink: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """column sums (bias gradients); with a sink the result is added into it and None is returned"""
     R = _lib.query("cvh_colreduce_rows", rows, C)
     part = _f32(R * 2 * C, x2d.device)
-    out = _f32(C, x2d.device)
-    _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), _p(out), 1.0, _stream())
-    return out
+    out = sink if sink is not None else _f32(C, x2d.device)
+    _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), _p(out), 1.0, 1 if sink is not None else 0, _stream())
+    return None if sink is not None else out
 
 
 def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentum, eps):
@@ -230,18 +328,22 @@ def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentu
     return stats
 
 
-def _bn_backward(y, dout, stats, gamma, act, rows, C, training, need_affine_grads=True):
-    """returns (dy_raw, dgamma, dbeta)."""
+def _bn_backward(y, dout, stats, gamma, act, rows, C, training, beta=None):
+    """returns (dy_raw, dgamma, dbeta); dgamma/dbeta are None when they were added in place into gamma.grad / beta.grad."""
     dev = y.device
     R = _lib.query("cvh_colreduce_rows", rows, C)
     part = _f32(R * 2 * C, dev)
     _lib.call("cvh_bn_bwd_reduce", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), act, rows, C, _p(part),
               _stream())
-    dgamma = _f32(C, dev)
-    dbeta = _f32(C, dev)
+    sg, sb = _grad_sink(gamma), _grad_sink(beta)
+    inplace = sg is not None and sb is not None
+    dgamma = sg if inplace else _f32(C, dev)
+    dbeta = sb if inplace else _f32(C, dev)
     coeff = _f32(3, dev, C)
-    _lib.call("cvh_bn_bwd_finalize", _p(part), R, C, float(rows), _p(gamma), _p(stats[0]), _p(stats[1]), 1 if training else 0, _p(dgamma),
-              _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
+    _lib.call("cvh_bn_bwd_finalize", _p(part), R, C, float(rows), _p(gamma), _p(stats[0]), _p(stats[1]), 1 if training else 0,
+              1 if inplace else 0, _p(dgamma), _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
+    if inplace:
+        dgamma = dbeta = None
     dy = torch.empty_like(y)
     _lib.call("cvh_bn_bwd_apply", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), act, _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _p(dy),
               rows, C, _stream())
@@ -276,6 +378,7 @@ class ConvBNAct(torch.autograd.Function):
         ctx.shapes = (B, C1, C2, H, W, Ho, Wo, Cout, Cin_real, KH, KW)
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
+        ctx.params = (bias, beta)  # parameter handles for in-place gradient accumulation
         if use_bn:
             part, R = None, 0
             if training:
@@ -301,15 +404,19 @@ class ConvBNAct(torch.autograd.Function):
         M = B * Ho * Wo
         dev, dtype = dout.device, dout.dtype
         dgamma = dbeta = dbias = None
+        bias_p, beta_p = ctx.params
         if use_bn:
-            dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, Cout, training)
+            dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, Cout, training, beta=beta_p)
         elif act != ACT_NONE:
             dy = _act_backward(y, dout, act, M, Cout)
         else:
             dy = dout
         if ctx.has_bias:
-            dbias = _colsum(dy, M, Cout)
-        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing: zero-fill for the atomic accumulation
+            dbias = _colsum(dy, M, Cout, _grad_sink(bias_p))
+        dw = _grad_sink(weight)
+        dw_ret = None
+        if dw is None:
+            dw = dw_ret = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing: zero-fill for the atomic accumulation
         _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real,
                   _stream())
         dx = dx2 = None
@@ -327,7 +434,7 @@ class ConvBNAct(torch.autograd.Function):
                 dx2 = nhwc_empty(B, C2, H, W, dtype, dev)
                 _conv_gemm(dy, None, Cout, 0, wpt, dx2, B, Ho, Wo, H, W, KH, KW, 1, pad_t, dil, C2, wp_offset=C1 * kk)
         dres = dout if ctx.has_res else None
-        return dx, dx2, dw, dbias, dgamma, dbeta, None, None, dres, None
+        return dx, dx2, dw_ret, dbias, dgamma, dbeta, None, None, dres, None
 
 
 def conv_bn_act(x, weight, bias=None, gamma=None, beta=None, rmean=None, rvar=None, *, stride=1, pad=0, dil=1, act=ACT_NONE,
@@ -356,6 +463,7 @@ class DWConvBNAct(torch.autograd.Function):
         y = nhwc_empty(B, C, Ho, Wo, dtype, dev)
         ctx.cfg = cfg
         ctx.shapes = (B, C, H, W, Ho, Wo, K)
+        ctx.beta = beta
         part, R = None, 0
         if use_bn and training:
             R = _lib.query("cvh_dwconv_rows", B, Ho, Wo, C, K, stride, pad, dil)
@@ -382,14 +490,16 @@ class DWConvBNAct(torch.autograd.Function):
         M = B * Ho * Wo
         dgamma = dbeta = None
         if use_bn:
-            dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, C, training)
+            dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, C, training, beta=ctx.beta)
         else:
             dy = dout
         R = _lib.query("cvh_dwconv_bwd_w_rows", B, Ho, Wo, C, K, stride, pad, dil)
         part = _f32(R * C * K * K, dev)
         _lib.call("cvh_dwconv_bwd_w", _dt(x), _p(x), _p(dy), _p(part), B, H, W, Ho, Wo, C, K, stride, pad, dil, _stream())
-        dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
-        _lib.call("cvh_sum_partials", _p(part), R, C * K * K, _p(dw), 1.0, _stream())
+        sink = _grad_sink(weight)
+        dw = None if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        _lib.call("cvh_sum_partials", _p(part), R, C * K * K, C * K * K, _p(sink if sink is not None else dw), 1.0,
+                  1 if sink is not None else 0, _stream())
         dx = None
         if ctx.needs_input_grad[0]:
             wp = pack_weight(weight, dtype, 2)
@@ -423,6 +533,7 @@ class BatchNormAct(torch.autograd.Function):
         out = torch.empty_like(x)
         _lib.call("cvh_bn_apply", _dt(x), _p(x), _p(stats[2]), _p(stats[3]), act, None, _p(out), M, C, _stream())
         ctx.cfg = cfg
+        ctx.beta = beta
         ctx.save_for_backward(x, stats, gamma)
         return out
 
@@ -431,7 +542,7 @@ class BatchNormAct(torch.autograd.Function):
         act, training, momentum, eps = ctx.cfg
         x, stats, gamma = ctx.saved_tensors
         B, C, H, W = x.shape
-        dx, dgamma, dbeta = _bn_backward(x, as_nhwc(dout), stats, gamma, act, B * H * W, C, training)
+        dx, dgamma, dbeta = _bn_backward(x, as_nhwc(dout), stats, gamma, act, B * H * W, C, training, beta=ctx.beta)
         return dx, dgamma, dbeta, None, None, None
 
 
@@ -460,6 +571,7 @@ class LinearAct(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
+        ctx.bias = bias
         ctx.save_for_backward(x, weight, pre)
         return out
 
@@ -477,8 +589,11 @@ class LinearAct(torch.autograd.Function):
             _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(dropout_seed(dev)), stream_id, _stream())
         if act != ACT_NONE:
             dy = _act_backward(pre, dy, act, rows, N)
-        dbias = _colsum(dy, rows, N) if ctx.has_bias else None
-        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing
+        dbias = _colsum(dy, rows, N, _grad_sink(ctx.bias)) if ctx.has_bias else None
+        dw = _grad_sink(weight)
+        dw_ret = None
+        if dw is None:
+            dw = dw_ret = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing
         _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), None, K, 0, _p(dw), rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K, _stream())
         dx = None
         if ctx.needs_input_grad[0]:
@@ -486,7 +601,7 @@ class LinearAct(torch.autograd.Function):
             dx = torch.empty((rows, K), dtype=dtype, device=dev)
             _conv_gemm(dy, None, N, 0, wpt, dx, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, K)
         dres = dout if ctx.has_res else None
-        return dx, dw, dbias, dres, None
+        return dx, dw_ret, dbias, dres, None
 
 
 def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None):
@@ -505,6 +620,7 @@ class LayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mr = _f32(2, x.device, rows)
         _lib.call("cvh_layernorm_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mr[0]), _p(mr[1]), rows, C, float(eps), _stream())
+        ctx.beta = beta
         ctx.save_for_backward(x, gamma, mr)
         return y
 
@@ -517,8 +633,13 @@ class LayerNormFn(torch.autograd.Function):
         part = _f32(R * 2 * C, x.device)
         dx = torch.empty_like(x)
         _lib.call("cvh_layernorm_bwd", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _stream())
+        sg, sb = _grad_sink(gamma), _grad_sink(ctx.beta)
+        if sg is not None and sb is not None:
+            _lib.call("cvh_sum_partials", _p(part), R, 2 * C, C, _p(sg), 1.0, 1, _stream())
+            _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, R, 2 * C, C, _p(sb), 1.0, 1, _stream())
+            return dx, None, None, None
         dgb = _f32(2 * C, x.device)
-        _lib.call("cvh_sum_partials", _p(part), R, 2 * C, _p(dgb), 1.0, _stream())
+        _lib.call("cvh_sum_partials", _p(part), R, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())
         return dx, dgb[:C], dgb[C:], None
 
 

@@ -146,3 +146,38 @@ def test_unsupported_variants_fail_loudly():
     m = cvnets_amd.MultiHeadAttention(64, 4).cuda()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(2, 8, 64, device="cuda"), x_kv=torch.zeros(2, 8, 64, device="cuda"))
+
+
+def test_inplace_param_grads_and_pack_plan_match_autograd_path():
+    """bench.py's fast path (flat gradient buckets written in place by the backward kernels + one-launch weight packing) must give
+    the same gradients as the plain autograd path, and a second step must see re-packed (updated) weights."""
+    import cvnets_amd
+    from cvnets_amd import ops
+    from cvnets_amd.ddp import DistributedDataParallel
+    from oracle.weights import seeded_input, seeded_labels
+
+    model, sd = _build("xx_small", torch.float32)
+    x = seeded_input((4, 3, 64, 64), seed=5).cuda()
+    y = seeded_labels(4, 1000, seed=5).cuda()
+    _, loss_ref, g_ref = _step(model, x, y)
+    model.load_state_dict(sd)
+    ddp = DistributedDataParallel(model, broadcast_buffers=False)
+    ops.set_inplace_param_grads(True)
+    try:
+        for it in range(2):
+            ddp.zero_grad()
+            model.train()
+            logits = model(x)
+            loss = F.cross_entropy(logits.float(), y, label_smoothing=0.1)
+            loss.backward()
+            if it == 0:
+                assert abs(float(loss) - loss_ref) < 1e-5
+                for k, p in model.named_parameters():
+                    assert l2_err(p.grad.cpu(), g_ref[k]) < 1e-4 or g_ref[k].norm() < 1e-7, k
+                with torch.no_grad():  # an "optimizer step": the next forward must use the new weights
+                    for p in model.parameters():
+                        p.mul_(0.5)
+            else:
+                assert abs(float(loss) - loss_ref) > 1e-3
+    finally:
+        ops.set_inplace_param_grads(False)

@@ -172,8 +172,9 @@ def test_inplace_param_grads_and_pack_plan_match_autograd_path():
             loss.backward()
             if it == 0:
                 assert abs(float(loss) - loss_ref) < 1e-5
-                for k, p in model.named_parameters():
-                    assert l2_err(p.grad.cpu(), g_ref[k]) < 1e-4 or g_ref[k].norm() < 1e-7, k
+                gmax = max(float(v.norm()) for v in g_ref.values())
+                for k, p in model.named_parameters():  # (mathematically-zero gradients, e.g. key biases, are pure round-off)
+                    assert l2_err(p.grad.cpu(), g_ref[k]) < 1e-4 or g_ref[k].norm() < 1e-5 * gmax, k
                 with torch.no_grad():  # an "optimizer step": the next forward must use the new weights
                     for p in model.parameters():
                         p.mul_(0.5)

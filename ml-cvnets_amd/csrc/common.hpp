@@ -197,6 +197,24 @@ __device__ __forceinline__ Frag<float> lds_frag(const float* tile, int pitch, in
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
   return f;
 }
+// same fragment from a tile whose rows are only 8-byte aligned (pitch % 4 == 0 elements): two ds_read_b64
+__device__ __forceinline__ Frag<bf16_t> lds_frag_a8(const bf16_t* tile, int pitch, int row0, int k0, int lane) {
+  const bf16_t* p = tile + (row0 + (lane & 31)) * pitch + k0 + 8 * (lane >> 5);
+  const uint2 a = *reinterpret_cast<const uint2*>(p);
+  const uint2 b = *reinterpret_cast<const uint2*>(p + 4);
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag_a8(const float* tile, int pitch, int row0, int k0, int lane) {
+  return lds_frag(tile, pitch, row0, k0, lane);
+}
+// XCD-aware block remap (MI355X: block b runs on XCD b % 8, each XCD has its own L2): give every XCD one CONTIGUOUS chunk of the
+// logical work list so that neighbouring work items (which share halo rows / operand panels) hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_chunk_id(int b, int n) {
+  const int q = n / 8, r = n % 8, x = b % 8, i = b / 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
 __device__ __forceinline__ void mma32(f32x16_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ 
   const int Wg = (p.Wo + TW - 1) / TW;
   const size_t ngroups = (size_t)p.B * p.Ho * Wg;
   if (pl < RL) {
-    for (size_t g = (size_t)blockIdx.x * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
+    for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
       const int wg = (int)(g % Wg);
       const size_t t1 = g / Wg;
       const int ho = (int)(t1 % p.Ho);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_x_s1_kernel(const T* __restri
   for (int t = 0; t < 9; ++t) v8_unpack(v8_load<T>(wp + (size_t)t * p.C + ci * 8), w[t]);
   const int Wg = (p.W + TW - 1) / TW;
   const size_t ngroups = (size_t)p.B * p.H * Wg;
-  for (size_t g = (size_t)blockIdx.x * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
+  for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
     const int wg = (int)(g % Wg);
     const size_t t1 = g / Wg;
     const int hi = (int)(t1 % p.H);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_x_s2_kernel(const T* __restri
   for (int t = 0; t < 9; ++t) v8_unpack(v8_load<T>(wp + (size_t)t * p.C + ci * 8), w[t]);
   const int Qh = (p.H + 1) / 2, Qw = (p.W + 1) / 2;
   const size_t nquads = (size_t)p.B * Qh * Qw;
-  for (size_t g = (size_t)blockIdx.x * RL + pl; g < nquads; g += (size_t)gridDim.x * RL) {
+  for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < nquads; g += (size_t)gridDim.x * RL) {
     const int qw = (int)(g % Qw);
     const size_t t1 = g / Qw;
     const int qh = (int)(t1 % Qh);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_w_kernel(const T* __restrict_
   const int Wg = (p.Wo + TW - 1) / TW;
   const size_t ngroups = (size_t)p.B * p.Ho * Wg;
   if (pl < RL) {
-    for (size_t g = (size_t)blockIdx.x * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
+    for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
       const int wg = (int)(g % Wg);
       const size_t t1 = g / Wg;
       const int ho = (int)(t1 % p.Ho);

@@ -324,7 +324,9 @@ __device__ __forceinline__ void store_transposed_pair(float* dst, int pitch, con
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
   constexpr int BMR = 32;
-  constexpr int PITCH = lds_pitch<T>(BMR);
+  // bf16: 72-byte rows put the 8-row-apart column chunks of a 32-lane write group on disjoint bank halves (the transposed
+  // row-pair stores become conflict-free); fragments are then read as two 8-byte halves.
+  constexpr int PITCH = sizeof(T) == 2 ? 36 : lds_pitch<T>(BMR);
   __shared__ __attribute__((aligned(16))) T Dt[128 * PITCH];
   __shared__ __attribute__((aligned(16))) T Xt[128 * PITCH];
 
@@ -409,10 +411,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         if (ms + PF * BMR < m_end) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ms + PF * BMR);
 #pragma unroll
         for (int kk = 0; kk < BMR; kk += 16) {
-          Frag<T> a0 = lds_frag(Dt, PITCH, wave_n * 64, kk, lane);
-          Frag<T> a1 = lds_frag(Dt, PITCH, wave_n * 64 + 32, kk, lane);
-          Frag<T> b0 = lds_frag(Xt, PITCH, wave_k * 64, kk, lane);
-          Frag<T> b1 = lds_frag(Xt, PITCH, wave_k * 64 + 32, kk, lane);
+          Frag<T> a0 = lds_frag_a8(Dt, PITCH, wave_n * 64, kk, lane);
+          Frag<T> a1 = lds_frag_a8(Dt, PITCH, wave_n * 64 + 32, kk, lane);
+          Frag<T> b0 = lds_frag_a8(Xt, PITCH, wave_k * 64, kk, lane);
+          Frag<T> b1 = lds_frag_a8(Xt, PITCH, wave_k * 64 + 32, kk, lane);
           mma32(acc[0][0], a0, b0);
           mma32(acc[0][1], a0, b1);
           mma32(acc[1][0], a1, b0);

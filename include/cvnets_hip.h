@@ -135,6 +135,9 @@ int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, 
                  const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
                  int causal, void* stream);
 
+/* experiment knob for tools/kernel_bench.py (A/B of kernel variants in one process); never needed for correct results */
+int cvh_set_tuning(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,6 +241,14 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
+// run-time tuning knobs (A/B experiments from tools/kernel_bench.py; defaults = shipped configuration)
+#define CVH_TUNE_TN_PITCH 1      /* 0: 80-byte rows + ds_read_b128, 1: 72-byte rows + 2 x ds_read_b64 */
+#define CVH_TUNE_TN_WGS 2        /* target number of gemm_tn workgroups */
+#define CVH_TUNE_GEMM_GRID 3     /* conv_gemm grid.x cap */
+#define CVH_TUNE_DW_XCD 4        /* depthwise: XCD-contiguous block mapping on/off */
+#define CVH_TUNE_MAX 16
+int cvh_tune_get(int key);
+
 #define CVH_CHECK_LAUNCH()                         \
   do {                                             \
     hipError_t e_ = hipGetLastError();             \

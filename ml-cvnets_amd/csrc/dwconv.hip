@@ -11,7 +11,9 @@
 
 struct DwParams {
   int B, H, W, Ho, Wo, C, K, stride, pad, dil;
+  int xcd;  // XCD-contiguous block mapping
 };
+__device__ __forceinline__ int dw_block(const DwParams& p) { return p.xcd ? xcd_chunk_id(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
 
 #define DW_TW 4
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void dwconv3_fwd_kernel(const T* __restrict__ 
   const int Wg = (p.Wo + TW - 1) / TW;
   const size_t ngroups = (size_t)p.B * p.Ho * Wg;
   if (pl < RL) {
-    for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
+    for (size_t g = (size_t)dw_block(p) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
       const int wg = (int)(g % Wg);
       const size_t t1 = g / Wg;
       const int ho = (int)(t1 % p.Ho);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_x_s1_kernel(const T* __restri
   for (int t = 0; t < 9; ++t) v8_unpack(v8_load<T>(wp + (size_t)t * p.C + ci * 8), w[t]);
   const int Wg = (p.W + TW - 1) / TW;
   const size_t ngroups = (size_t)p.B * p.H * Wg;
-  for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
+  for (size_t g = (size_t)dw_block(p) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
     const int wg = (int)(g % Wg);
     const size_t t1 = g / Wg;
     const int hi = (int)(t1 % p.H);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_x_s2_kernel(const T* __restri
   for (int t = 0; t < 9; ++t) v8_unpack(v8_load<T>(wp + (size_t)t * p.C + ci * 8), w[t]);
   const int Qh = (p.H + 1) / 2, Qw = (p.W + 1) / 2;
   const size_t nquads = (size_t)p.B * Qh * Qw;
-  for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < nquads; g += (size_t)gridDim.x * RL) {
+  for (size_t g = (size_t)dw_block(p) * RL + pl; g < nquads; g += (size_t)gridDim.x * RL) {
     const int qw = (int)(g % Qw);
     const size_t t1 = g / Qw;
     const int qh = (int)(t1 % Qh);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_w_kernel(const T* __restrict_
   const int Wg = (p.Wo + TW - 1) / TW;
   const size_t ngroups = (size_t)p.B * p.Ho * Wg;
   if (pl < RL) {
-    for (size_t g = (size_t)xcd_chunk_id(blockIdx.x, gridDim.x) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
+    for (size_t g = (size_t)dw_block(p) * RL + pl; g < ngroups; g += (size_t)gridDim.x * RL) {
       const int wg = (int)(g % Wg);
       const size_t t1 = g / Wg;
       const int ho = (int)(t1 % p.Ho);
@@ -465,7 +467,7 @@ extern "C" int cvh_dwconv_bwd_w_rows(int B, int Ho, int Wo, int C, int K, int st
 extern "C" int cvh_dwconv_fwd(int dtype, const void* x, const void* wp, void* y, int B, int H, int W, int Ho, int Wo, int C, int K,
                               int stride, int pad, int dil, float* stats_part, void* stream) {
   if (C % 8 || C > 2048 || K != 3) return -2;
-  DwParams p{B, H, W, Ho, Wo, C, K, stride, pad, dil};
+  DwParams p{B, H, W, Ho, Wo, C, K, stride, pad, dil, cvh_tune_get(CVH_TUNE_DW_XCD)};
   hipStream_t st = (hipStream_t)stream;
   const bool fast = dw_fast(K, stride, pad, dil);
   const int g = cvh_dwconv_rows(B, Ho, Wo, C, K, stride, pad, dil);
@@ -485,7 +487,7 @@ extern "C" int cvh_dwconv_fwd(int dtype, const void* x, const void* wp, void* y,
 extern "C" int cvh_dwconv_bwd_x(int dtype, const void* dy, const void* wp, void* dx, int B, int H, int W, int Ho, int Wo, int C, int K,
                                 int stride, int pad, int dil, void* stream) {
   if (C % 8 || C > 2048 || K != 3) return -2;
-  DwParams p{B, H, W, Ho, Wo, C, K, stride, pad, dil};
+  DwParams p{B, H, W, Ho, Wo, C, K, stride, pad, dil, cvh_tune_get(CVH_TUNE_DW_XCD)};
   hipStream_t st = (hipStream_t)stream;
   const bool fast = dw_fast(K, stride, pad, dil);
   if (fast && stride == 1) {
@@ -511,7 +513,7 @@ extern "C" int cvh_dwconv_bwd_x(int dtype, const void* dy, const void* wp, void*
 extern "C" int cvh_dwconv_bwd_w(int dtype, const void* x, const void* dy, float* part, int B, int H, int W, int Ho, int Wo, int C, int K,
                                 int stride, int pad, int dil, void* stream) {
   if (C % 8 || C > 2048 || K != 3) return -2;
-  DwParams p{B, H, W, Ho, Wo, C, K, stride, pad, dil};
+  DwParams p{B, H, W, Ho, Wo, C, K, stride, pad, dil, cvh_tune_get(CVH_TUNE_DW_XCD)};
   hipStream_t st = (hipStream_t)stream;
   const bool fast = dw_fast(K, stride, pad, dil);
   const int g = cvh_dwconv_bwd_w_rows(B, Ho, Wo, C, K, stride, pad, dil);

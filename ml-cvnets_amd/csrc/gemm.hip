@@ -321,12 +321,12 @@ __device__ __forceinline__ void store_transposed_pair(float* dst, int pitch, con
   for (int j = 0; j < 8; ++j) *reinterpret_cast<float2*>(dst + j * pitch) = make_float2(a[j], b[j]);
 }
 
-template <typename T>
+template <typename T, int PV>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
   constexpr int BMR = 32;
   // bf16: 72-byte rows put the 8-row-apart column chunks of a 32-lane write group on disjoint bank halves (the transposed
   // row-pair stores become conflict-free); fragments are then read as two 8-byte halves.
-  constexpr int PITCH = sizeof(T) == 2 ? 36 : lds_pitch<T>(BMR);
+  constexpr int PITCH = (sizeof(T) == 2 && PV == 1) ? 36 : lds_pitch<T>(BMR);
   __shared__ __attribute__((aligned(16))) T Dt[128 * PITCH];
   __shared__ __attribute__((aligned(16))) T Xt[128 * PITCH];
 
@@ -411,10 +411,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         if (ms + PF * BMR < m_end) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ms + PF * BMR);
 #pragma unroll
         for (int kk = 0; kk < BMR; kk += 16) {
-          Frag<T> a0 = lds_frag_a8(Dt, PITCH, wave_n * 64, kk, lane);
-          Frag<T> a1 = lds_frag_a8(Dt, PITCH, wave_n * 64 + 32, kk, lane);
-          Frag<T> b0 = lds_frag_a8(Xt, PITCH, wave_k * 64, kk, lane);
-          Frag<T> b1 = lds_frag_a8(Xt, PITCH, wave_k * 64 + 32, kk, lane);
+          Frag<T> a0 = PV == 1 ? lds_frag_a8(Dt, PITCH, wave_n * 64, kk, lane) : lds_frag(Dt, PITCH, wave_n * 64, kk, lane);
+          Frag<T> a1 = PV == 1 ? lds_frag_a8(Dt, PITCH, wave_n * 64 + 32, kk, lane) : lds_frag(Dt, PITCH, wave_n * 64 + 32, kk, lane);
+          Frag<T> b0 = PV == 1 ? lds_frag_a8(Xt, PITCH, wave_k * 64, kk, lane) : lds_frag(Xt, PITCH, wave_k * 64, kk, lane);
+          Frag<T> b1 = PV == 1 ? lds_frag_a8(Xt, PITCH, wave_k * 64 + 32, kk, lane) : lds_frag(Xt, PITCH, wave_k * 64 + 32, kk, lane);
           mma32(acc[0][0], a0, b0);
           mma32(acc[0][1], a0, b1);
           mma32(acc[1][0], a1, b0);
@@ -451,7 +451,8 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   ConvGemmParams p = p0;
   p.m_tiles = (p.M + BM - 1) / BM;
   const int n_tiles = (p.N + BN - 1) / BN;
-  int gx = p.m_tiles < 512 ? p.m_tiles : 512;
+  const int cap = cvh_tune_get(CVH_TUNE_GEMM_GRID);
+  int gx = p.m_tiles < cap ? p.m_tiles : cap;
   dim3 grid(gx, n_tiles);
   constexpr int TILE_ELEMS = (BM + BN) * lds_pitch<T>(BK);
   constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
@@ -499,7 +500,8 @@ extern "C" int cvh_conv_gemm_grid_rows(int M, int N) {
   // number of stats-partial rows conv_gemm writes for an (M, N) problem (== gridDim.x)
   (void)N;
   int mt = (M + 127) / 128;
-  return mt < 512 ? mt : 512;
+  const int cap = cvh_tune_get(CVH_TUNE_GEMM_GRID);
+  return mt < cap ? mt : cap;
 }
 
 extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2, const void* wgt, void* out,
@@ -541,7 +543,8 @@ extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const vo
   p.k_tiles = (p.Ktot + 127) / 128;
   const int out_tiles = n_tiles * p.k_tiles;
   // enough splits over M to put ~2 deep-prefetching workgroups on every CU (fewer splits = fewer fp32 atomics)
-  int splits = (512 + out_tiles - 1) / out_tiles;
+  const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS);
+  int splits = (target_wgs + out_tiles - 1) / out_tiles;
   int max_splits = (p.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -551,8 +554,10 @@ extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const vo
   p.m_per_split = mps;
   dim3 grid(out_tiles, splits);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 0, st, p);
-  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, p);
+  if (dtype == CVH_DT_BF16) {
+    if (cvh_tune_get(CVH_TUNE_TN_PITCH)) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0>), grid, dim3(256), 0, st, p);
+  } else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0>), grid, dim3(256), 0, st, p);
   else return -1;
   CVH_CHECK_LAUNCH();
   return 0;

@@ -55,6 +55,7 @@ SIGNATURES = {
     "cvh_layernorm_fwd": [I, P, P, P, P, P, P, L, I, F, P],
     "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
     "cvh_ln_bwd_rows": [L],
+    "cvh_set_tuning": [I, I],
     "cvh_attn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
 }

@@ -62,11 +62,14 @@ int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2,
                   const void* residual, float drop_p, const unsigned long long* seed, unsigned int stream_id,
                   float* stats_part, void* stream);
 int cvh_conv_gemm_grid_rows(int M, int N);
-/* dW[N][Cin_real][KH][KW] (float32, torch layout, must be zeroed) += dY[M][N]^T x im2col(src)[M][K].
- * Replaces the weight-gradient half of Conv2d / Linear backward. */
+/* dW[N][Cin_real][KH][KW] (float32, torch layout) = (accumulate ? dW : 0) + dY[M][N]^T x im2col(src)[M][K].  The M range is split
+ * over workgroups; with `scratch` (>= cvh_gemm_dw_scratch_elems(M, N, K) floats) every split stores its partial tile and a second
+ * kernel sums them (no atomics); with scratch == NULL the splits add into dW with fp32 atomics (accumulate must be 1 and dW zeroed /
+ * holding the running gradient).  Replaces the weight-gradient half of Conv2d / Linear backward. */
 int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw,
                 int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
-                int Cin_real, void* stream);
+                int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream);
+long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot);
 
 /* ---- depthwise 3x3 conv (groups == C) ----------------------------------------------------------- */
 /* Replaces nn.Conv2d(groups=C) in InvertedResidual (cvnets/modules/mobilenetv2.py:194-207). */

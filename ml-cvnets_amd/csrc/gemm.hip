@@ -302,6 +302,7 @@ struct GemmTNParams {
   int Cin_real;
   int m_per_split;
   int k_tiles;
+  float* part;  // [splits][N][Ktot] partial products (no atomics); nullptr -> fp32 atomics straight into dw
 };
 
 __device__ __forceinline__ void store_transposed_pair(bf16_t* dst, int pitch, const V8<bf16_t>& r0, const V8<bf16_t>& r1) {
@@ -431,6 +432,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     for (int fk = 0; fk < 2; ++fk) {
       const int k = k0 + wave_k * 64 + fk * 32 + (lane & 31);
       if (k >= p.Ktot) continue;
+      if (p.part) {  // plain coalesced stores of this split's partial tile; gemm_dw_reduce_kernel sums the splits
+        float* dst = p.part + (size_t)blockIdx.y * p.N * p.Ktot + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
+          if (n < p.N) dst[(size_t)n * p.Ktot] = acc[fn][fk][r];
+        }
+        continue;
+      }
       int t2 = 0, c2 = k;
       if (!pointwise) { t2 = k / Cin; c2 = k - t2 * Cin; }
       if (c2 >= p.Cin_real) continue;
@@ -440,6 +450,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         if (n < p.N) atomicAdd(p.dw + ((size_t)n * p.Cin_real + c2) * khw + t2, acc[fn][fk][r]);
       }
     }
+}
+
+// dw[n][c][tap] (torch layout) = (or +=) sum over splits of part[split][n][tap*Cin + c]
+__global__ void gemm_dw_reduce_kernel(const float* __restrict__ part, int splits, int N, int Ktot, int Cin, int Cin_real, int khw,
+                                      float* __restrict__ dw, int accumulate) {
+  const size_t total = (size_t)N * Ktot;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Ktot);
+    const int n = (int)(idx / Ktot);
+    const int tap = k / Cin, c = k - tap * Cin;
+    if (c >= Cin_real) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
+    float* d = dw + ((size_t)n * Cin_real + c) * khw + tap;
+    *d = accumulate ? *d + s : s;
+  }
 }
 
 // =============================================================================================
@@ -530,28 +556,50 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   return -1;
 }
 
+static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* splits, int* mps) {
+  const int n_tiles = (N + 127) / 128;
+  *k_tiles = (Ktot + 127) / 128;
+  *out_tiles = n_tiles * *k_tiles;
+  // enough splits over M to put ~2 deep-prefetching workgroups on every CU
+  const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS);
+  int sp = (target_wgs + *out_tiles - 1) / *out_tiles;
+  int max_splits = (M + 255) / 256;
+  if (sp > max_splits) sp = max_splits;
+  if (sp < 1) sp = 1;
+  int m = (M + sp - 1) / sp;
+  m = ((m + 31) / 32) * 32;
+  *splits = (M + m - 1) / m;
+  *mps = m;
+}
+
+extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
+  if (M <= 0) return 0;
+  int ot, kt, sp, mps;
+  tn_plan(M, N, Ktot, &ot, &kt, &sp, &mps);
+  return (long long)sp * N * Ktot;
+}
+
 extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw,
                            int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
-                           int Cin_real, void* stream) {
+                           int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream) {
   if ((C1 % 8) != 0 || (C2 % 8) != 0 || (N % 8) != 0) return -2;
   GemmTNParams p;
   p.dy = dy; p.src1 = src1; p.src2 = src2; p.C1 = C1; p.C2 = C2; p.dw = dw;
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.M = B * Ho * Wo; p.N = N; p.Ktot = KH * KW * (C1 + C2); p.Cin_real = Cin_real;
   if (p.M <= 0) return 0;
-  const int n_tiles = (N + 127) / 128;
-  p.k_tiles = (p.Ktot + 127) / 128;
-  const int out_tiles = n_tiles * p.k_tiles;
-  // enough splits over M to put ~2 deep-prefetching workgroups on every CU (fewer splits = fewer fp32 atomics)
-  const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS);
-  int splits = (target_wgs + out_tiles - 1) / out_tiles;
-  int max_splits = (p.M + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int mps = (p.M + splits - 1) / splits;
-  mps = ((mps + 31) / 32) * 32;
-  splits = (p.M + mps - 1) / mps;
+  int out_tiles, splits, mps;
+  tn_plan(p.M, N, p.Ktot, &out_tiles, &p.k_tiles, &splits, &mps);
   p.m_per_split = mps;
+  // scratch path: every split writes its partial tile, one reduce kernel sums them (assign or accumulate into dw).
+  // Without scratch: fp32 atomics into dw, which the caller must have zeroed (accumulate semantics only).
+  p.part = nullptr;
+  if (scratch != nullptr) {
+    if (scratch_elems < (long long)splits * N * p.Ktot) return -2;
+    p.part = scratch;
+  } else if (!accumulate) {
+    return -2;
+  }
   dim3 grid(out_tiles, splits);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CVH_DT_BF16) {
@@ -560,5 +608,12 @@ extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const vo
   } else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0>), grid, dim3(256), 0, st, p);
   else return -1;
   CVH_CHECK_LAUNCH();
+  if (p.part) {
+    const size_t total = (size_t)N * p.Ktot;
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3(g), dim3(256), 0, st, p.part, splits, N, p.Ktot, C1 + C2, Cin_real, KH * KW, dw, accumulate);
+    CVH_CHECK_LAUNCH();
+  }
   return 0;
 }

@@ -29,7 +29,8 @@ SIGNATURES = {
     "cvh_cast_to_f32": [I, P, P, L, P],
     "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
     "cvh_conv_gemm_grid_rows": [I, I],
-    "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
+    "cvh_gemm_dw_scratch_elems": [I, I, I],
     "cvh_dwconv_fwd": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "cvh_dwconv_rows": [I, I, I, I, I, I, I, I],
     "cvh_dwconv_bwd_x": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
@@ -81,7 +82,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name.endswith("_elems") else c_int
     _lib = lib
     return lib
 

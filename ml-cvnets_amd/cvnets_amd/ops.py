@@ -316,6 +316,18 @@ def _colsum(x2d: torch.Tensor, rows: int, C: int, sink: Optional[torch.Tensor] =
     return None if sink is not None else out
 
 
+def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real):
+    """dW = dY^T x im2col(x): split over M into a scratch buffer + one reduce kernel (no atomics, no zero-fill).  Returns the
+    gradient tensor, or None when it was added in place into weight.grad."""
+    sink = _grad_sink(weight)
+    dw = sink if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
+    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", B * Ho * Wo, N, KH * KW * (C1 + C2))
+    scr = _f32(max(n_scr, 1), dy.device)
+    _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real,
+              _p(scr), n_scr, 1 if sink is not None else 0, _stream())
+    return None if sink is not None else dw
+
+
 def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentum, eps):
     """returns stats [4][C] = (mean, invstd, scale, shift)."""
     stats = _f32(4, y.device, C)
@@ -413,12 +425,7 @@ class ConvBNAct(torch.autograd.Function):
             dy = dout
         if ctx.has_bias:
             dbias = _colsum(dy, M, Cout, _grad_sink(bias_p))
-        dw = _grad_sink(weight)
-        dw_ret = None
-        if dw is None:
-            dw = dw_ret = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing: zero-fill for the atomic accumulation
-        _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real,
-                  _stream())
+        dw_ret = _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real)
         dx = dx2 = None
         need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
         if need1 or need2:
@@ -590,11 +597,7 @@ class LinearAct(torch.autograd.Function):
         if act != ACT_NONE:
             dy = _act_backward(pre, dy, act, rows, N)
         dbias = _colsum(dy, rows, N, _grad_sink(ctx.bias)) if ctx.has_bias else None
-        dw = _grad_sink(weight)
-        dw_ret = None
-        if dw is None:
-            dw = dw_ret = torch.zeros(weight.shape, dtype=torch.float32, device=dev)  # plumbing
-        _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), None, K, 0, _p(dw), rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K, _stream())
+        dw_ret = _weight_grad(dy, x, None, K, 0, weight, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K)
         dx = None
         if ctx.needs_input_grad[0]:
             wpt = pack_weight(weight, dtype, 1)  # [K][N]

@@ -17,7 +17,7 @@ def header_prototypes():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(cvh_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long long)\s+(cvh_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         name, args = m.group(1), m.group(2)
         types = []
         for a in args.split(","):

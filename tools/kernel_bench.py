@@ -88,8 +88,10 @@ def bench_all(B, reps, only):
                     add("conv_gemm dX", name, f"M={M} K={k * k * Cout} N={Cin}", us, (x.numel() + y.numel()) * ES)
             if "tn" in only:
                 dw = torch.zeros(Cout, Cin, k, k, device="cuda")
+                n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, Cout, k * k * Cin)
+                scr = torch.empty(max(n_scr, 1), device="cuda")
                 us = timeit(lambda: _lib.call("cvh_gemm_dw", 1, y.data_ptr(), x.data_ptr(), None, Cin, 0, dw.data_ptr(), B, H, H, Ho, Ho, k, k,
-                                               stride, pad, 1, Cout, Cin, s()), reps)
+                                               stride, pad, 1, Cout, Cin, scr.data_ptr(), n_scr, 0, s()), reps)
                 add("gemm_tn dW", name, f"M={M} N={Cout} K={k * k * Cin}", us, (x.numel() + y.numel()) * ES)
         for name, rpi, K, N in LINEARS:
             M = B * rpi
@@ -101,8 +103,10 @@ def bench_all(B, reps, only):
                 add("conv_gemm fwd", name, f"M={M} K={K} N={N}", us, (x.numel() + y.numel()) * ES)
             if "tn" in only:
                 dw = torch.zeros(N, K, device="cuda")
+                n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, N, K)
+                scr = torch.empty(max(n_scr, 1), device="cuda")
                 us = timeit(lambda: _lib.call("cvh_gemm_dw", 1, y.data_ptr(), x.data_ptr(), None, K, 0, dw.data_ptr(), M, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K,
-                                               s()), reps)
+                                               scr.data_ptr(), n_scr, 0, s()), reps)
                 add("gemm_tn dW", name, f"M={M} N={N} K={K}", us, (x.numel() + y.numel()) * ES)
     if "dw" in only:
         for name, C, H, stride in DWS:

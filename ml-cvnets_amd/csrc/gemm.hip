@@ -452,19 +452,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     }
 }
 
-// dw[n][c][tap] (torch layout) = (or +=) sum over splits of part[split][n][tap*Cin + c]
-__global__ void gemm_dw_reduce_kernel(const float* __restrict__ part, int splits, int N, int Ktot, int Cin, int Cin_real, int khw,
-                                      float* __restrict__ dw, int accumulate) {
+// dw[n][c][tap] (torch layout) = (or +=) sum over splits of part[split][n][tap*Cin + c].
+// Block = 16 consecutive output elements x 16 split lanes (the split loop is the long dimension for pointwise convs).
+__global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __restrict__ part, int splits, int N, int Ktot, int Cin, int Cin_real,
+                                                             int khw, float* __restrict__ dw, int accumulate) {
+  __shared__ float red[16][17];
   const size_t total = (size_t)N * Ktot;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % Ktot);
-    const int n = (int)(idx / Ktot);
-    const int tap = k / Cin, c = k - tap * Cin;
-    if (c >= Cin_real) continue;
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
-    float* d = dw + ((size_t)n * Cin_real + c) * khw + tap;
-    *d = accumulate ? *d + s : s;
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (size_t base = (size_t)blockIdx.x * 16; base < total; base += (size_t)gridDim.x * 16) {
+    const size_t idx = base + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < total) {
+      int sp = sl;
+      for (; sp + 48 < splits; sp += 64) {
+        s0 += part[(size_t)sp * total + idx];
+        s1 += part[(size_t)(sp + 16) * total + idx];
+        s2 += part[(size_t)(sp + 32) * total + idx];
+        s3 += part[(size_t)(sp + 48) * total + idx];
+      }
+      for (; sp < splits; sp += 16) s0 += part[(size_t)sp * total + idx];
+    }
+    red[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && idx < total) {
+      float s = 0.f;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) s += red[l][e];
+      const int k = (int)(idx % Ktot);
+      const int n = (int)(idx / Ktot);
+      const int tap = k / Cin, c = k - tap * Cin;
+      if (c < Cin_real) {
+        float* d = dw + ((size_t)n * Cin_real + c) * khw + tap;
+        *d = accumulate ? *d + s : s;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -610,8 +632,8 @@ extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const vo
   CVH_CHECK_LAUNCH();
   if (p.part) {
     const size_t total = (size_t)N * p.Ktot;
-    int g = (int)((total + 255) / 256);
-    if (g > 2048) g = 2048;
+    int g = (int)((total + 15) / 16);
+    if (g > 4096) g = 4096;
     hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3(g), dim3(256), 0, st, p.part, splits, N, p.Ktot, C1 + C2, Cin_real, KH * KW, dw, accumulate);
     CVH_CHECK_LAUNCH();
   }

@@ -209,6 +209,13 @@ __device__ __forceinline__ Frag<bf16_t> lds_frag_a8(const bf16_t* tile, int pitc
 __device__ __forceinline__ Frag<float> lds_frag_a8(const float* tile, int pitch, int row0, int k0, int lane) {
   return lds_frag(tile, pitch, row0, k0, lane);
 }
+// ordering of LDS traffic between the lanes of ONE wave (per-wave private LDS regions): LDS operations of a wave execute in
+// program order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // XCD-aware block remap (MI355X: block b runs on XCD b % 8, each XCD has its own L2): give every XCD one CONTIGUOUS chunk of the
 // logical work list so that neighbouring work items (which share halo rows / operand panels) hit the same L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_chunk_id(int b, int n) {

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int SP = stage_pitch<T, NF>();
   constexpr int TILE_ELEMS = (BM + BN) * PITCH;
   constexpr int STAGE_ELEMS = 4 * 32 * SP;
-  constexpr int MAIN_ELEMS = TILE_ELEMS > STAGE_ELEMS ? TILE_ELEMS : STAGE_ELEMS;
+  constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
   using SG = StageGroups<NF>;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  T* stg = As + wave * (32 * SP);  // per-wave output staging, aliases the operand tiles after the K loop
+  T* stg = As + TILE_ELEMS + wave * (32 * SP);  // per-wave PRIVATE output staging: the epilogue needs only wave-level ordering
   const int n0 = blockIdx.y * BN;
   const int Cin = p.C1 + p.C2;
   const T* __restrict__ src1 = reinterpret_cast<const T*>(p.src1);
@@ -99,6 +99,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   int a_b[A_IT], a_h[A_IT], a_w[A_IT];
   bool a_ok[A_IT];
   V8<T> ra[A_IT], rb[B_IT];
+  // single K step (pointwise convs with Cin <= BK): the weight tile is staged ONCE per workgroup, not once per M tile
+  const bool b_resident = p.Ktot <= BK;
+  if (b_resident) {
+    const int k = ccol * 8;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int q = tid + i * 256;
+      int n = n0 + q / CPR;
+      V8<T> v = v8_zero<T>();
+      if (q < BN * CPR && n < p.N && k < p.Ktot) v = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
+      if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, v);
+    }
+  }
 
   auto decode_rows = [&](int m0) {
 #pragma unroll
@@ -141,13 +154,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
         }
       }
     }
+    if (!b_resident) {
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int q = tid + i * 256;
-      int r = q / CPR;
-      int n = n0 + r;
-      rb[i] = v8_zero<T>();
-      if (q < BN * CPR && n < p.N && kok) rb[i] = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
+      for (int i = 0; i < B_IT; ++i) {
+        int q = tid + i * 256;
+        int r = q / CPR;
+        int n = n0 + r;
+        rb[i] = v8_zero<T>();
+        if (q < BN * CPR && n < p.N && kok) rb[i] = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
+      }
     }
   };
   auto store_tiles = [&]() {
@@ -156,10 +171,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
       int q = tid + i * 256;
       if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, ra[i]);
     }
+    if (!b_resident) {
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int q = tid + i * 256;
-      if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, rb[i]);
+      for (int i = 0; i < B_IT; ++i) {
+        int q = tid + i * 256;
+        if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, rb[i]);
+      }
     }
   };
 
@@ -199,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 
     // ---- epilogue: accumulators -> (bias) -> per-wave LDS staging -> coalesced 16 B/lane rows with the fused
     //      activation / act-grad / dropout / residual / BatchNorm statistics ----
-    __syncthreads();  // every wave is done reading As/Bs, which the staging area aliases
     static_for<0, SG::n>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       constexpr int F0 = SG::start[g], GW = SG::width[g];
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) stg[acc_row(r, lane) * SP + fl * 32 + (lane & 31)] = from_f<T>(acc[f][r] + bias);
       });
-      __syncthreads();
+      wave_lds_sync();
       const int ch = lane % CH;
       const int n = n0 + F0 * 32 + ch * 8;
       if (n < p.N) {
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
           }
         }
       }
-      __syncthreads();  // staging consumed before the next group / next tile overwrites it
+      wave_lds_sync();  // staging consumed before the next group / next tile overwrites it
     });
   }
 
@@ -504,7 +520,7 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   dim3 grid(gx, n_tiles);
   constexpr int TILE_ELEMS = (BM + BN) * lds_pitch<T>(BK);
   constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
-  constexpr int MAIN_ELEMS = TILE_ELEMS > STAGE_ELEMS ? TILE_ELEMS : STAGE_ELEMS;
+  constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
   size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)2 * BN * sizeof(float);
   auto kern = conv_gemm_kernel<T, NF, BK>;
   if (smem > 64 * 1024) {
@@ -583,7 +599,8 @@ static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* s
   *k_tiles = (Ktot + 127) / 128;
   *out_tiles = n_tiles * *k_tiles;
   // enough splits over M to put ~2 deep-prefetching workgroups on every CU
-  const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS);
+  // (K-heavy 3x3 problems have many output tiles and long per-split MFMA chains: they like twice as many workgroups)
+  const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS) * (*out_tiles >= 8 ? 2 : 1);
   int sp = (target_wgs + *out_tiles - 1) / *out_tiles;
   int max_splits = (M + 255) / 256;
   if (sp > max_splits) sp = max_splits;

@@ -21,11 +21,14 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                             // round-to-nearest-even
-  return (uint16_t)(u >> 16);
+// f32 -> bf16, round-to-nearest-even: native __bf16 conversions lower to the gfx950 hardware v_cvt_pk_bf16_f32 (one VALU op per
+// PAIR instead of ~6 integer ops per value — the GEMM epilogues were VALU-bound on the bit-twiddling version).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T x);
@@ -91,7 +94,7 @@ __device__ __forceinline__ void v8_unpack(const V8<float>& v, float* f) {
 __device__ __forceinline__ void v8_pack(const float* f, V8<bf16_t>& v) {
   uint32_t w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(f[2 * i]) | ((uint32_t)f2bf(f[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = f2bf_pk(f[2 * i], f[2 * i + 1]);
   v.d = make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ __forceinline__ void v8_pack(const float* f, V8<float>& v) {
@@ -106,8 +109,8 @@ __device__ __forceinline__ void v4_unpack(const V4<float>& v, float* f) {
   f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w;
 }
 __device__ __forceinline__ void v4_pack(const float* f, V4<bf16_t>& v) {
-  v.d.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-  v.d.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  v.d.x = f2bf_pk(f[0], f[1]);
+  v.d.y = f2bf_pk(f[2], f[3]);
 }
 __device__ __forceinline__ void v4_pack(const float* f, V4<float>& v) { v.a = make_float4(f[0], f[1], f[2], f[3]); }
 

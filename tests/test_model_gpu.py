@@ -72,7 +72,7 @@ def test_train_step_vs_reference_golden(name, mode, batch, res, dtype):
     print(f"[{name} {dtype}] logits rel-L2 eval {e_eval:.2e} train {e_train:.2e} loss {loss:.5f} vs {float(gold['loss']):.5f}")
     assert e_eval < (1e-4 if fp32 else 3e-2), e_eval
     assert e_train < (1e-4 if fp32 else BF16_SLACK * ref_bf16["logits_train"]), (e_train, ref_bf16)
-    assert abs(loss - float(gold["loss"])) < (1e-4 if fp32 else max(1e-2, BF16_SLACK * ref_bf16["loss"]))
+    assert abs(loss - float(gold["loss"])) < (1e-4 if fp32 else max(2e-2, BF16_SLACK * ref_bf16["loss"]))
     names = [str(n) for n in gold["grad_names"]]
     assert names == [k for k, _ in model.named_parameters()]
     gn = torch.tensor([grads[k].norm().item() for k in names], dtype=torch.float64)

@@ -39,7 +39,7 @@ int cvh_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H,
 int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cs, void* stream);
 /* Parameter packing (float32 torch layout [Cout][Cin][KH][KW] -> `dtype`).  mode 0: forward pack
  * [Cout][KH*KW][pad8(Cin)];  mode 1: dX pack (transposed, taps flipped) [Cin][KH*KW][pad8(Cout)];
- * mode 2: depthwise [KH*KW][C].  Replaces autocast's per-call weight cast (engine/utils.py:19-36). */
+ * mode 2: depthwise [KH*KW][C];  mode 3: patch-dX pack [KH*KW][pad8(Cin)][pad8(Cout)] (kernel == stride convs).  Replaces autocast's per-call weight cast (engine/utils.py:19-36). */
 int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, int Cin, int KHW, int mode, void* stream);
 /* every conv / linear weight of a model packed by ONE launch: table = n_entries x {src ptr, dst element offset, Cout, Cin, KHW,
  * mode, first global element} (int64, device memory), out = flat `dtype` buffer. */
@@ -70,6 +70,10 @@ int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, i
                 int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
                 int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream);
 long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot);
+/* dX of a non-overlapping strided conv (kernel == stride, pad 0: ViT patch-embedding convs, cvnets/models/classification/vit.py:89-123):
+ * dx[B][H][W][Cin] = scatter(dy[B*Ho*Wo][Cout] x wgt^T), wgt = mode-3 pack. */
+int cvh_conv_dx_patch(int dtype, const void* dy, const void* wgt, void* dx, int B, int Ho, int Wo, int Cout, int KH, int KW,
+                      int stride, int Cin, int H, int W, void* stream);
 
 /* ---- depthwise 3x3 conv (groups == C) ----------------------------------------------------------- */
 /* Replaces nn.Conv2d(groups=C) in InvertedResidual (cvnets/modules/mobilenetv2.py:194-207). */
@@ -118,6 +122,20 @@ int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void*
  * multiple of the patch (cvnets/modules/mobilevit_block.py:191-200, 260-266); bwd = exact adjoint (gather form). */
 int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, void* stream);
 int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, void* stream);
+
+/* ---- token plumbing for ViT / CLIP --------------------------------------------------------------- */
+/* out[b][0] = cls, out[b][1+n] = patch[b][n] + pos[n]  (cls == NULL: no class token).  VisionTransformer.extract_patch_embeddings,
+ * cvnets/models/classification/vit.py:480-509.  bwd: dpatch = rows of dout; dcls / dpos via cvh_batch_sum over the batch. */
+int cvh_vit_embed_fwd(int dtype, const void* patch, const float* pos, const float* cls, void* out, int B, int N, int E, void* stream);
+int cvh_vit_embed_bwd(int dtype, const void* dout, void* dpatch, int B, int N, int E, int has_cls, void* stream);
+int cvh_batch_sum(int dtype, const void* x, float* out, int B, long long L, int accumulate, void* stream);
+/* dst[r][0:C] = src[r][0:C] with independent row strides (class-token rows, vit.py:562-565) */
+int cvh_rows_copy(int dtype, const void* src, void* dst, long long rows, int C, long long src_stride, long long dst_stride, void* stream);
+/* text tower: out[r] = table[tok[r]] + pos[r % S] (cvnets/text_encoders/transformer.py:321-341); bwd scatter-adds into dtable */
+int cvh_embed_lookup_fwd(int dtype, const long long* tok, const float* table, const float* pos, void* out, long long rows, int S, int E,
+                         void* stream);
+int cvh_embed_lookup_bwd(int dtype, const long long* tok, const void* dout, float* dtable, long long rows, int E, long long padding_idx,
+                         void* stream);
 
 /* ---- LayerNorm over channels -------------------------------------------------------------------- */
 /* Replaces nn.LayerNorm, channel-last branch (cvnets/layers/normalization/layer_norm.py:67-68). */

@@ -51,6 +51,7 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict_
 //   mode 0 (forward):   out[n][tap*Cp + c]            = w[n][c][tap]          rows = Cout, Cp = pad8(Cin)
 //   mode 1 (dX, s=1):   out[c][tap*Np + n]            = w[n][c][KH*KW-1-tap]  rows = Cin (transposed, taps flipped), Np = pad8(Cout)
 //   mode 2 (depthwise): out[tap*C + c]                = w[c][0][tap]
+//   mode 3 (patch dX):  out[tap*Cp + c][n]            = w[n][c][tap]          rows = (tap, c), Np = pad8(Cout)  (kernel == stride convs)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void weight_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KHW, int Cp, int Np,
@@ -58,6 +59,7 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, T* __restrict__ 
   size_t total;
   if (mode == 0) total = (size_t)Cout * KHW * Cp;
   else if (mode == 1) total = (size_t)Cin * KHW * Np;
+  else if (mode == 3) total = (size_t)KHW * Cp * Np;
   else total = (size_t)KHW * Cout;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     float v = 0.f;
@@ -73,6 +75,12 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, T* __restrict__ 
       int tap = (int)(t % KHW);
       int c = (int)(t / KHW);
       if (n < Cout) v = w[((size_t)n * Cin + c) * KHW + (KHW - 1 - tap)];
+    } else if (mode == 3) {
+      int n = (int)(idx % Np);
+      size_t t = idx / Np;
+      int c = (int)(t % Cp);
+      int tap = (int)(t / Cp);
+      if (n < Cout && c < Cin) v = w[((size_t)n * Cin + c) * KHW + tap];
     } else {
       int c = (int)(idx % Cout);
       int tap = (int)(idx / Cout);
@@ -108,6 +116,11 @@ __global__ void weight_pack_multi_kernel(const long long* __restrict__ table, in
       const long long t = li / Np;
       const int tap = (int)(t % KHW), c = (int)(t / KHW);
       if (nn < Cout) v = w[((size_t)nn * Cin + c) * KHW + (KHW - 1 - tap)];
+    } else if (mode == 3) {
+      const int nn = (int)(li % Np);
+      const long long t = li / Np;
+      const int c = (int)(t % Cp), tap = (int)(t / Cp);
+      if (nn < Cout && c < Cin) v = w[((size_t)nn * Cin + c) * KHW + tap];
     } else {
       const int c = (int)(li % Cout), tap = (int)(li / Cout);
       v = w[(size_t)c * KHW + tap];
@@ -590,7 +603,7 @@ extern "C" int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, in
 }
 extern "C" int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, int Cin, int KHW, int mode, void* stream) {
   const int Cp = (Cin + 7) / 8 * 8, Np = (Cout + 7) / 8 * 8;
-  size_t total = mode == 0 ? (size_t)Cout * KHW * Cp : (mode == 1 ? (size_t)Cin * KHW * Np : (size_t)KHW * Cout);
+  size_t total = mode == 0 ? (size_t)Cout * KHW * Cp : (mode == 1 ? (size_t)Cin * KHW * Np : (mode == 3 ? (size_t)KHW * Cp * Np : (size_t)KHW * Cout));
   DISPATCH_T(dtype, hipLaunchKernelGGL((weight_pack_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w, (T*)out, Cout, Cin, KHW, Cp, Np, mode);)
   CVH_CHECK_LAUNCH();
   return 0;

@@ -32,6 +32,9 @@ struct ConvGemmParams {
   unsigned int stream_id;
   float* stats_part;
   int m_tiles;
+  // output scatter (dX of a non-overlapping strided conv, kernel == stride, pad 0): GEMM row m = (b, ho, wo) of the sc_Ho x sc_Wo
+  // map, column n = (kh, kw, c) -> out[b][ho*sc_s + kh][wo*sc_s + kw][c] of a sc_H x sc_W x sc_C map.  sc_s == 0: plain [M][N] output.
+  int sc_s, sc_KW, sc_C, sc_H, sc_W, sc_Ho, sc_Wo;
 };
 
 // staging-group decomposition of the NF accumulator fragments of a wave: groups of 4 / 2 / 1 fragments so that the
@@ -238,7 +241,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
           const int row = pass * RPP + lane / CH;
           const int m = m0 + wave * 32 + row;
           if (m < p.M) {
-            const size_t o = (size_t)m * p.N + n;
+            size_t o = (size_t)m * p.N + n;
+            if (p.sc_s) {
+              const int hw = p.sc_Ho * p.sc_Wo;
+              const int b = m / hw, rem = m - b * hw;
+              const int ho = rem / p.sc_Wo, wo = rem - ho * p.sc_Wo;
+              const int tap = n / p.sc_C, c = n - tap * p.sc_C;
+              const int kh = tap / p.sc_KW, kw = tap - kh * p.sc_KW;
+              o = (((size_t)b * p.sc_H + ho * p.sc_s + kh) * p.sc_W + wo * p.sc_s + kw) * p.sc_C + c;
+            }
             V8<T> pv = v8_load<T>(stg + row * SP + ch * 8);
             if (p.save_pre) v8_store<T>(reinterpret_cast<T*>(p.save_pre) + o, pv);
             float v[8];
@@ -582,6 +593,7 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   p.bias = bias; p.act = act; p.save_pre = save_pre; p.actgrad_aux = actgrad_aux; p.actgrad_act = actgrad_act;
   p.residual = residual; p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id; p.stats_part = stats_part;
   p.m_tiles = 0;
+  p.sc_s = 0; p.sc_KW = p.sc_C = p.sc_H = p.sc_W = p.sc_Ho = p.sc_Wo = 0;
   if (p.M <= 0 || N <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int nf = choose_nf(N);
@@ -591,6 +603,33 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   } else if (dtype == CVH_DT_F32) {
     return dispatch_conv_gemm_nf<float, 32>(p, nf, st);
   }
+  return -1;
+}
+
+// dX of a non-overlapping strided conv (kernel == stride, pad 0; the ViT patch-embedding convs, cvnets/models/classification/vit.py:89-123):
+// every input pixel belongs to exactly one window, so dX = scatter( dY[M][Cout] x Wp3[(kh,kw,c)][Cout]^T ) — one GEMM whose
+// epilogue writes each 8-channel chunk to its pixel.  wgt = mode-3 pack.  Pixels outside every window (H > Ho*s) are zeroed first.
+extern "C" int cvh_conv_dx_patch(int dtype, const void* dy, const void* wgt, void* dx, int B, int Ho, int Wo, int Cout, int KH, int KW,
+                                 int stride, int Cin, int H, int W, void* stream) {
+  if ((Cout % 8) != 0 || (Cin % 8) != 0 || KH != stride || KW != stride || Ho * stride > H || Wo * stride > W) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == CVH_DT_BF16 ? 2 : 4;
+  if (Ho * stride != H || Wo * stride != W) {
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * H * W * Cin * esz, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  ConvGemmParams p;
+  p.src1 = dy; p.src2 = nullptr; p.C1 = Cout; p.C2 = 0; p.wgt = wgt; p.out = dx;
+  p.B = B * Ho * Wo; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.M = B * Ho * Wo; p.N = KH * KW * Cin; p.Ktot = Cout;
+  p.bias = nullptr; p.act = 0; p.save_pre = nullptr; p.actgrad_aux = nullptr; p.actgrad_act = 0; p.residual = nullptr;
+  p.drop_p = 0.f; p.seed = nullptr; p.stream_id = 0; p.stats_part = nullptr; p.m_tiles = 0;
+  p.sc_s = stride; p.sc_KW = KW; p.sc_C = Cin; p.sc_H = H; p.sc_W = W; p.sc_Ho = Ho; p.sc_Wo = Wo;
+  if (p.M <= 0) return 0;
+  const int nf = choose_nf(p.N);
+  const bool bk64 = p.Ktot >= 64;
+  if (dtype == CVH_DT_BF16) return bk64 ? dispatch_conv_gemm_nf<bf16_t, 64>(p, nf, st) : dispatch_conv_gemm_nf<bf16_t, 32>(p, nf, st);
+  if (dtype == CVH_DT_F32) return dispatch_conv_gemm_nf<float, 32>(p, nf, st);
   return -1;
 }
 

@@ -1,0 +1,175 @@
+// Token-matrix plumbing for the ViT / CLIP stacks (all HBM-bound, 16 B per lane):
+//   * patch tokens + positional embedding + class token  ->  [B][1+N][E] sequence   (fwd / bwd)
+//   * batch reduction of a [B][L] gradient (class-token / positional-embedding gradients)
+//   * strided row copy (class-token rows in / out of a [B][S][E] tensor)
+//   * embedding lookup + positional embedding for the text tower, and its scatter-add backward
+//
+// Replaces (reference): VisionTransformer.extract_patch_embeddings cvnets/models/classification/vit.py:480-509,
+// the cls split :562-565, TextTransformer.forward_embedding cvnets/text_encoders/transformer.py:321-341.
+#include "common.hpp"
+#include "cvnets_hip.h"
+
+// out[b][0][:] = cls[:] ; out[b][1+n][:] = patch[b][n][:] + pos[n][:]      (has_cls == 0: out[b][n] = patch + pos)
+template <typename T>
+__global__ void vit_embed_fwd_kernel(const T* __restrict__ patch, const float* __restrict__ pos, const float* __restrict__ cls, T* __restrict__ out,
+                                     int B, int N, int E, int has_cls) {
+  const int eg = E / 8;
+  const int S = N + has_cls;
+  const size_t total = (size_t)B * S * eg;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e0 = (int)(idx % eg) * 8;
+    const size_t t = idx / eg;
+    const int sidx = (int)(t % S);
+    const size_t b = t / S;
+    float f[8];
+    if (has_cls && sidx == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = cls[e0 + j];
+    } else {
+      const int n = sidx - has_cls;
+      v8_unpack(v8_load<T>(patch + (b * N + n) * E + e0), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += pos[(size_t)n * E + e0 + j];
+    }
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(out + idx * 8, o);
+  }
+}
+
+// dpatch[b][n][:] = dout[b][has_cls + n][:]
+template <typename T>
+__global__ void vit_embed_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dpatch, int B, int N, int E, int has_cls) {
+  const int eg = E / 8;
+  const int S = N + has_cls;
+  const size_t total = (size_t)B * N * eg;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e0 = (int)(idx % eg) * 8;
+    const size_t t = idx / eg;
+    const int n = (int)(t % N);
+    const size_t b = t / N;
+    v8_store<T>(dpatch + idx * 8, v8_load<T>(dout + (b * S + n + has_cls) * E + e0));
+  }
+}
+
+// out[j] (+)= sum_b x[b*L + j]   (fp32 result; L % 8 == 0)
+template <typename T>
+__global__ void batch_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int B, size_t L, int accumulate) {
+  const size_t lg = L / 8;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < lg; g += (size_t)gridDim.x * blockDim.x) {
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < B; ++b) {
+      float f[8];
+      v8_unpack(v8_load<T>(x + (size_t)b * L + g * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[g * 8 + j] = accumulate ? out[g * 8 + j] + s[j] : s[j];
+  }
+}
+
+// dst[r*dst_stride + c] = src[r*src_stride + c], c < C (C % 8 == 0)
+template <typename T>
+__global__ void rows_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, size_t rows, int C, size_t src_stride, size_t dst_stride) {
+  const int cg = C / 8;
+  const size_t total = rows * cg;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % cg) * 8;
+    const size_t r = idx / cg;
+    v8_store<T>(dst + r * dst_stride + c0, v8_load<T>(src + r * src_stride + c0));
+  }
+}
+
+// text tower: out[b][s][:] = table[tok[b][s]][:] + pos[s][:]
+template <typename T>
+__global__ void embed_lookup_fwd_kernel(const long long* __restrict__ tok, const float* __restrict__ table, const float* __restrict__ pos,
+                                        T* __restrict__ out, size_t rows, int S, int E) {
+  const int eg = E / 8;
+  const size_t total = rows * eg;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e0 = (int)(idx % eg) * 8;
+    const size_t r = idx / eg;
+    const long long t = tok[r];
+    const int sp = (int)(r % S);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = table[(size_t)t * E + e0 + j] + (pos ? pos[(size_t)sp * E + e0 + j] : 0.f);
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(out + idx * 8, o);
+  }
+}
+// dtable[tok[r]][:] += dout[r][:]   (fp32 atomics: repeated tokens collide by design)
+template <typename T>
+__global__ void embed_lookup_bwd_kernel(const long long* __restrict__ tok, const T* __restrict__ dout, float* __restrict__ dtable, size_t rows, int E,
+                                        long long padding_idx) {
+  const int eg = E / 8;
+  const size_t total = rows * eg;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e0 = (int)(idx % eg) * 8;
+    const size_t r = idx / eg;
+    const long long t = tok[r];
+    if (t == padding_idx) continue;
+    float f[8];
+    v8_unpack(v8_load<T>(dout + idx * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(dtable + (size_t)t * E + e0 + j, f[j]);
+  }
+}
+
+static inline int tk_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define TK_DISPATCH(dtype, ...)                                   \
+  if ((dtype) == CVH_DT_BF16) { using T = bf16_t; __VA_ARGS__ }   \
+  else if ((dtype) == CVH_DT_F32) { using T = float; __VA_ARGS__ } \
+  else return -1;
+
+extern "C" int cvh_vit_embed_fwd(int dtype, const void* patch, const float* pos, const float* cls, void* out, int B, int N, int E, void* stream) {
+  if (E % 8) return -2;
+  const int has_cls = cls != nullptr;
+  const size_t total = (size_t)B * (N + has_cls) * (E / 8);
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((vit_embed_fwd_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)patch, pos, cls, (T*)out, B, N, E, has_cls);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_vit_embed_bwd(int dtype, const void* dout, void* dpatch, int B, int N, int E, int has_cls, void* stream) {
+  if (E % 8) return -2;
+  const size_t total = (size_t)B * N * (E / 8);
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((vit_embed_bwd_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)dpatch, B, N, E, has_cls);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_batch_sum(int dtype, const void* x, float* out, int B, long long L, int accumulate, void* stream) {
+  if (L % 8) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((batch_sum_kernel<T>), dim3(tk_grid((size_t)L / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, out, B, (size_t)L, accumulate);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_rows_copy(int dtype, const void* src, void* dst, long long rows, int C, long long src_stride, long long dst_stride, void* stream) {
+  if (C % 8 || src_stride % 8 || dst_stride % 8) return -2;
+  const size_t total = (size_t)rows * (C / 8);
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((rows_copy_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, (size_t)rows, C, (size_t)src_stride, (size_t)dst_stride);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_embed_lookup_fwd(int dtype, const long long* tok, const float* table, const float* pos, void* out, long long rows, int S, int E,
+                                    void* stream) {
+  if (E % 8) return -2;
+  const size_t total = (size_t)rows * (E / 8);
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((embed_lookup_fwd_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, tok, table, pos, (T*)out, (size_t)rows, S, E);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_embed_lookup_bwd(int dtype, const long long* tok, const void* dout, float* dtable, long long rows, int E, long long padding_idx,
+                                    void* stream) {
+  if (E % 8) return -2;
+  const size_t total = (size_t)rows * (E / 8);
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((embed_lookup_bwd_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, tok, (const T*)dout, dtable, (size_t)rows, E, padding_idx);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

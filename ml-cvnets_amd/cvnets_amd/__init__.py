@@ -5,8 +5,8 @@ state_dict keys; compute: hand-written HIP kernels for gfx950 in libcvnets_hip.s
 """
 from . import _lib, ops  # noqa: F401
 from .layers import (BatchNorm2d, Conv2d, ConvLayer2d, Dropout, GELU, GlobalPool, Identity, LayerNorm, LinearLayer,  # noqa: F401
-                     MultiHeadAttention, Swish, build_activation_layer, default_opts, get_normalization_layer)
-from .models import MobileViT, build_mobilevit, get_configuration  # noqa: F401
+                     MultiHeadAttention, PositionalEmbedding, Swish, build_activation_layer, default_opts, get_normalization_layer)
+from .models import MobileViT, VisionTransformer, build_mobilevit, build_vit, get_configuration  # noqa: F401
 from .modules import InvertedResidual, MobileViTBlock, TransformerEncoder  # noqa: F401
 from .ops import compute_dtype, set_compute_dtype  # noqa: F401
 

@@ -57,6 +57,13 @@ SIGNATURES = {
     "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
     "cvh_ln_bwd_rows": [L],
     "cvh_set_tuning": [I, I],
+    "cvh_conv_dx_patch": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cvh_vit_embed_fwd": [I, P, P, P, P, I, I, I, P],
+    "cvh_vit_embed_bwd": [I, P, P, I, I, I, I, P],
+    "cvh_batch_sum": [I, P, P, I, L, I, P],
+    "cvh_rows_copy": [I, P, P, L, I, L, L, P],
+    "cvh_embed_lookup_fwd": [I, P, P, P, P, L, I, I, P],
+    "cvh_embed_lookup_bwd": [I, P, P, P, L, I, L, P],
     "cvh_attn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
 }

@@ -33,6 +33,9 @@ _BY_NAME = {
     "TransformerEncoder": modules.TransformerEncoder,
     "MobileViTBlock": modules.MobileViTBlock,
     "MobileViT": models.MobileViT,
+    "VisionTransformer": models.VisionTransformer,
+    "PositionalEmbedding": layers.PositionalEmbedding,
+    "LearnablePositionalEmbedding": layers.LearnablePositionalEmbedding,
 }
 
 

@@ -46,6 +46,13 @@ def default_opts(**overrides) -> argparse.Namespace:
         "model.activation.inplace": False,
         "model.activation.neg_slope": 0.1,
         "model.layer.global_pool": "mean",
+        "model.classification.vit.mode": "tiny",
+        "model.classification.vit.dropout": 0.0,
+        "model.classification.vit.norm_layer": "layer_norm",
+        "model.classification.vit.no_cls_token": False,
+        "model.classification.vit.stochastic_dropout": 0.0,
+        "model.classification.vit.sinusoidal_pos_emb": False,
+        "model.classification.vit.use_pytorch_mha": False,
     }
     base.update(overrides)
     for k, v in base.items():
@@ -315,6 +322,60 @@ class GlobalPool(nn.Module):
 
     def __repr__(self):
         return "{}(type={})".format(self.__class__.__name__, self.pool_type)
+
+
+# ---------------------------------------------------------------------------------------------
+# positional embedding  (cvnets/layers/positional_embedding.py:16-180; learnable variant only)
+# ---------------------------------------------------------------------------------------------
+class LearnablePositionalEmbedding(nn.Module):
+    def __init__(self, opts, num_embeddings: int, embedding_dim: int, padding_idx: Optional[int] = None, sequence_first: Optional[bool] = False,
+                 interpolation_mode: Optional[str] = "bilinear", *args, **kwargs):
+        super().__init__()
+        self.pos_embed = nn.Parameter(torch.empty(1, 1, num_embeddings, embedding_dim))
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        self.padding_idx = padding_idx
+        self.sequence_first = sequence_first
+        self.interpolation_mode = interpolation_mode
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.trunc_normal_(self.pos_embed, mean=0, std=self.embedding_dim ** -0.5)
+        if self.padding_idx is not None:
+            with torch.no_grad():
+                self.pos_embed[:, :, self.padding_idx, ...] = 0.0
+
+    def forward(self, seq_len: int, *args, **kwargs) -> Tensor:
+        """returns the [seq_len, E] float32 table (bilinearly resized along the sequence axis when seq_len differs,
+        positional_embedding.py:90-95); the batch broadcast happens inside the embedding kernel."""
+        if self.padding_idx is not None or self.interpolation_mode != "bilinear":
+            raise NotImplementedError("padding_idx / non-bilinear positional embeddings are not on the HIP hot path")
+        pe = self.pos_embed.view(self.num_embeddings, self.embedding_dim)
+        if seq_len != self.num_embeddings:
+            # [N, E] is an NHWC map with H = N, W = 1, C = E: resizing H only is F.interpolate(size=(seq_len, E)) on [1,1,N,E]
+            fm = pe.view(1, self.num_embeddings, 1, self.embedding_dim).permute(0, 3, 1, 2)
+            pe = ops.resize_bilinear(fm, seq_len, 1).permute(0, 2, 3, 1).reshape(seq_len, self.embedding_dim)
+        return pe
+
+    def __repr__(self):
+        return "{}(num_embeddings={}, embedding_dim={}, padding_idx={}, sequence_first={})".format(
+            self.__class__.__name__, self.num_embeddings, self.embedding_dim, self.padding_idx, self.sequence_first)
+
+
+class PositionalEmbedding(nn.Module):
+    def __init__(self, opts, num_embeddings: int, embedding_dim: int, padding_idx: Optional[int] = None, is_learnable: Optional[bool] = False,
+                 sequence_first: Optional[bool] = False, interpolation_mode: Optional[str] = "bilinear", *args, **kwargs):
+        super().__init__()
+        if not is_learnable:
+            raise NotImplementedError("sinusoidal positional embeddings are not on the HIP hot path")
+        self.pos_embed = LearnablePositionalEmbedding(opts, num_embeddings=num_embeddings, embedding_dim=embedding_dim, padding_idx=padding_idx,
+                                                      sequence_first=sequence_first, interpolation_mode=interpolation_mode)
+
+    def forward(self, seq_len: int, *args, **kwargs) -> Tensor:
+        return self.pos_embed(seq_len, *args, **kwargs)
+
+    def __repr__(self):
+        return self.pos_embed.__repr__()
 
 
 # ---------------------------------------------------------------------------------------------

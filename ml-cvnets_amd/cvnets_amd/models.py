@@ -136,3 +136,111 @@ def build_mobilevit(mode: str = "small", opts=None, **overrides) -> MobileViT:
     if opts is None:
         opts = default_opts(**{"model.classification.mit.mode": mode}, **overrides)
     return MobileViT(opts)
+
+
+# =============================================================================================
+# ViT  (cvnets/models/classification/vit.py:33-649, config/vit.py:12-99)
+# =============================================================================================
+def get_vit_configuration(opts) -> Dict:
+    mode = (opt(opts, "model.classification.vit.mode", "tiny") or "tiny").lower()
+    dropout = opt(opts, "model.classification.vit.dropout", 0.0)
+    norm_layer = opt(opts, "model.classification.vit.norm_layer", "layer_norm")
+    table = {"tiny": (192, 12, 3, 0.1), "small": (384, 12, 6, 0.0), "base": (768, 12, 12, 0.0), "large": (1024, 24, 16, 0.0),
+             "huge": (1280, 32, 20, 0.0)}
+    if mode not in table:
+        raise NotImplementedError(f"Got unsupported ViT configuration: {mode}")
+    e, n, h, pdrop = table[mode]
+    return {"embed_dim": e, "n_transformer_layers": n, "n_attn_heads": h, "ffn_dim": 4 * e, "norm_layer": norm_layer,
+            "pos_emb_drop_p": pdrop, "attn_dropout": 0.0, "ffn_dropout": 0.0, "dropout": dropout}
+
+
+class VisionTransformer(nn.Module):
+    """Conv-stem ViT of the reference: 3 patch-embedding convs (k4s4 / k2s2 / k2s2) -> + learnable positional embedding, class token
+    (no positional embedding on it) -> N x TransformerEncoder -> LayerNorm(eps 1e-6) -> class-token classifier.
+    Gradient checkpointing (vit.yaml:81) is a memory-saving re-execution of the same kernels and is not needed with 288 GB of HBM."""
+
+    def __init__(self, opts, *args, **kwargs) -> None:
+        super().__init__()
+        from .layers import PositionalEmbedding, get_normalization_layer
+        from .modules import TransformerEncoder
+
+        num_classes = opt(opts, "model.classification.n_classes", 1000)
+        if opt(opts, "model.classification.vit.use_pytorch_mha", False):
+            raise NotImplementedError("use_pytorch_mha is not on the HIP hot path")
+        cfg = get_vit_configuration(opts)
+        embed_dim, norm_layer = cfg["embed_dim"], cfg["norm_layer"]
+        num_embeddings = (224 // 16) ** 2
+        stem_dim = max(32, embed_dim // 4)
+        self.patch_emb = nn.Sequential(
+            ConvLayer2d(opts=opts, in_channels=3, out_channels=stem_dim, kernel_size=4, stride=4, bias=False, use_norm=True, use_act=True),
+            ConvLayer2d(opts=opts, in_channels=stem_dim, out_channels=stem_dim, kernel_size=2, stride=2, bias=False, use_norm=True, use_act=True),
+            ConvLayer2d(opts=opts, in_channels=stem_dim, out_channels=embed_dim, kernel_size=2, stride=2, bias=True, use_norm=False, use_act=False),
+        )
+        if opt(opts, "model.classification.vit.stochastic_dropout", 0.0) > 0.0:
+            raise NotImplementedError("StochasticDepth is not on the HIP hot path")
+        blocks = [TransformerEncoder(opts=opts, embed_dim=embed_dim, ffn_latent_dim=cfg["ffn_dim"], num_heads=cfg["n_attn_heads"],
+                                     attn_dropout=cfg["attn_dropout"], dropout=cfg["dropout"], ffn_dropout=cfg["ffn_dropout"],
+                                     transformer_norm_layer=norm_layer, stochastic_dropout=0.0)
+                  for _ in range(cfg["n_transformer_layers"])]
+        self.post_transformer_norm = get_normalization_layer(opts=opts, num_features=embed_dim, norm_type=norm_layer)
+        self.transformer = nn.Sequential(*blocks)
+        self.classifier = LinearLayer(embed_dim, num_classes)
+        if not opt(opts, "model.classification.vit.no_cls_token", False):
+            self.cls_token = nn.Parameter(torch.zeros(size=(1, 1, embed_dim)))
+            torch.nn.init.trunc_normal_(self.cls_token, std=0.02)
+        else:
+            self.cls_token = None
+        self.pos_embed = PositionalEmbedding(opts=opts, num_embeddings=num_embeddings, embedding_dim=embed_dim, sequence_first=False,
+                                             padding_idx=None,
+                                             is_learnable=not opt(opts, "model.classification.vit.sinusoidal_pos_emb", False),
+                                             interpolation_mode="bilinear")
+        self.emb_dropout = Dropout(p=cfg["pos_emb_drop_p"])
+        self.embed_dim = embed_dim
+        self.n_classes = num_classes
+        for m in self.modules():  # vit.py:204-208 update_layer_norm_eps
+            if isinstance(m, nn.LayerNorm):
+                m.eps = 1e-6
+
+    def extract_patch_embeddings(self, x: Tensor):
+        if self.training:
+            ops.advance_dropout_seed(x.device)
+            ops.pack_all(self)
+        fm = self.patch_emb(ops.to_nhwc(x))
+        B, E, n_h, n_w = fm.shape
+        N = n_h * n_w
+        pos = self.pos_embed(N)
+        cls = self.cls_token.view(E) if self.cls_token is not None else None
+        t = ops.VitEmbed.apply(ops.tokens_of(fm), pos, cls, B)
+        t = ops.dropout(t, self.emb_dropout.p, self.training)
+        return t, B, N + (1 if cls is not None else 0), (n_h, n_w)
+
+    def extract_features(self, x: Tensor, *args, **kwargs):
+        if kwargs.get("return_image_embeddings", False):
+            raise NotImplementedError("return_image_embeddings (dense-prediction heads) is not on the HIP hot path")
+        t, B, S, _ = self.extract_patch_embeddings(x)
+        seqmap = (B, S, 1, 1, S, 1, S)
+        for layer in self.transformer:
+            t = layer.forward_tokens(t, seqmap)
+        n = self.post_transformer_norm
+        t = ops.layer_norm(t, n.weight, n.bias, n.eps)
+        if self.cls_token is None:
+            raise NotImplementedError("mean-pooled ViT (no_cls_token) is not on the HIP hot path")
+        return ops.RowsGather.apply(t, B, S, 0), None
+
+    def forward_classifier(self, x: Tensor, *args, **kwargs):
+        cls_embedding, image_embedding = self.extract_features(x, *args, **kwargs)
+        return self.classifier(cls_embedding), image_embedding
+
+    def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
+        prediction, _ = self.forward_classifier(x, *args, **kwargs)
+        return prediction
+
+
+def build_vit(mode: str = "tiny", opts=None, **overrides) -> VisionTransformer:
+    from .layers import default_opts
+
+    if opts is None:
+        base = {"model.classification.vit.mode": mode, "model.activation.name": "gelu"}
+        base.update(overrides)
+        opts = default_opts(**base)
+    return VisionTransformer(opts)

@@ -175,6 +175,8 @@ def _pack_numel(shape, mode: int) -> int:
         return Cout * KHW * pad8(Cin)
     if mode == 1:
         return Cin * KHW * pad8(Cout)
+    if mode == 3:
+        return KHW * pad8(Cin) * pad8(Cout)
     return KHW * Cout
 
 
@@ -191,6 +193,8 @@ class PackPlan:
                     entries.append((w, 0))
                     if m.stride[0] == 1:
                         entries.append((w, 1))
+                    elif m.stride[0] == m.kernel_size[0] and m.padding[0] == 0 and m.in_channels % 8 == 0:
+                        entries.append((w, 3))
                 elif m.groups == m.in_channels == m.out_channels:
                     entries.append((w, 2))
             elif hasattr(m, "weight") and isinstance(getattr(m, "weight", None), torch.nn.Parameter) and m.weight.dim() == 2 \
@@ -270,12 +274,7 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, mode: int) -> torch.Tensor:
         Cout, Cin, KHW = wf.shape[0], wf.shape[1], 1
     else:
         Cout, Cin, KHW = wf.shape[0], wf.shape[1], wf.shape[2] * wf.shape[3]
-    if mode == 0:
-        n = Cout * KHW * pad8(Cin)
-    elif mode == 1:
-        n = Cin * KHW * pad8(Cout)
-    else:
-        n = KHW * Cout
+    n = _pack_numel(wf.shape, mode)
     out = torch.empty(n, dtype=dtype, device=w.device)
     _lib.call("cvh_weight_pack", _dt(out), _p(wf), _p(out), Cout, Cin, KHW, mode, _stream())
     return out
@@ -430,7 +429,14 @@ class ConvBNAct(torch.autograd.Function):
         need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
         if need1 or need2:
             if stride != 1:
-                raise NotImplementedError("dX of a strided dense conv is not on the hot path (only the stem is strided)")
+                # non-overlapping patch convs (kernel == stride, pad 0: the ViT stem) -> one GEMM with a scatter epilogue
+                if not (KH == KW == stride and pad == 0 and dil == 1 and x2 is None):
+                    raise NotImplementedError("dX of an overlapping strided dense conv is not on the hot path (only MobileViT's stem, which needs none)")
+                wp3 = pack_weight(weight, dtype, 3)  # [(kh,kw,c)][Cout]
+                dx = nhwc_empty(B, C1, H, W, dtype, dev)
+                _lib.call("cvh_conv_dx_patch", _dt(dy), _p(dy), _p(wp3), _p(dx), B, Ho, Wo, Cout, KH, KW, stride, C1, H, W, _stream())
+                dres = dout if ctx.has_res else None
+                return dx, None, dw_ret, dbias, dgamma, dbeta, None, None, dres, None
             wpt = pack_weight(weight, dtype, 1)  # [Cin][KH*KW][Cout]
             pad_t = dil * (KH - 1) - pad
             kk = KH * KW * Cout
@@ -742,6 +748,54 @@ class ResizeBilinear(torch.autograd.Function):
 
 def resize_bilinear(x, Ho: int, Wo: int):
     return ResizeBilinear.apply(x, int(Ho), int(Wo))
+
+
+class VitEmbed(torch.autograd.Function):
+    """patch tokens + positional embedding (+ class token)  ->  [B*(1+N), E]   (vit.py:480-509).  pos [N,E] / cls [E] are fp32."""
+
+    @staticmethod
+    def forward(ctx, patch, pos, cls, B):
+        _check_dev(patch)
+        N, E = pos.shape
+        S = N + (1 if cls is not None else 0)
+        out = torch.empty((B * S, E), dtype=patch.dtype, device=patch.device)
+        _lib.call("cvh_vit_embed_fwd", _dt(patch), _p(patch), _p(pos), _p(cls), _p(out), B, N, E, _stream())
+        ctx.meta = (B, N, E, cls is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, E, has_cls = ctx.meta
+        S = N + (1 if has_cls else 0)
+        dout = dout.contiguous()
+        dpatch = torch.empty((B * N, E), dtype=dout.dtype, device=dout.device)
+        _lib.call("cvh_vit_embed_bwd", _dt(dout), _p(dout), _p(dpatch), B, N, E, 1 if has_cls else 0, _stream())
+        dsum = _f32(S * E, dout.device)
+        _lib.call("cvh_batch_sum", _dt(dout), _p(dout), _p(dsum), B, S * E, 0, _stream())
+        if has_cls:
+            return dpatch, dsum[E:].view(N, E), dsum[:E], None
+        return dpatch, dsum.view(N, E), None, None
+
+
+class RowsGather(torch.autograd.Function):
+    """x [B*S, E] -> rows b*S + idx (one per sequence), e.g. the class-token embeddings (vit.py:562-565)."""
+
+    @staticmethod
+    def forward(ctx, x, B, S, idx):
+        _check_dev(x)
+        E = x.shape[1]
+        y = torch.empty((B, E), dtype=x.dtype, device=x.device)
+        _lib.call("cvh_rows_copy", _dt(x), x.data_ptr() + idx * E * x.element_size(), _p(y), B, E, S * E, E, _stream())
+        ctx.meta = (B, S, E, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, S, E, idx = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.zeros((B * S, E), dtype=dy.dtype, device=dy.device)  # plumbing: every other row has zero gradient
+        _lib.call("cvh_rows_copy", _dt(dy), _p(dy), dx.data_ptr() + idx * E * dx.element_size(), B, E, E, S * E, _stream())
+        return dx, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):

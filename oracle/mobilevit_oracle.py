@@ -87,6 +87,7 @@ def conv_bn_act(
     bn_state: Optional[BNState] = None,
     momentum: float = 0.1,
     eps: float = 1e-5,
+    act: str = "swish",
 ) -> Tensor:
     """ConvLayer2d.forward = Sequential{conv, norm?, act?}  (cvnets/layers/conv_layer.py:254-255).
 
@@ -109,7 +110,7 @@ def conv_bn_act(
             bn_state.running[prefix + ".block.norm.running_mean"] = rm
             bn_state.running[prefix + ".block.norm.running_var"] = rv
     if use_act:
-        y = F.silu(y)
+        y = F.silu(y) if act == "swish" else F.gelu(y)
     return y
 
 
@@ -279,4 +280,50 @@ def train_step(sd: Dict[str, Tensor], x: Tensor, y: Tensor, mode: str = "small",
     loss = cross_entropy(logits, y, label_smoothing)
     names = [k for k, v in params.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [params[k] for k in names])
+    return logits.detach(), loss.detach(), dict(zip(names, grads)), st.running
+
+
+# --------------------------------------------------------------------------------------
+# ViT  (cvnets/models/classification/vit.py:33-649)
+# --------------------------------------------------------------------------------------
+VIT_CFG = {"tiny": (192, 12, 3), "small": (384, 12, 6), "base": (768, 12, 12)}  # config/vit.py:12-99: (embed, layers, heads); ffn = 4*embed
+
+
+def positional_embedding(sd, prefix: str, seq_len: int) -> Tensor:
+    """LearnablePositionalEmbedding.forward (cvnets/layers/positional_embedding.py:81-104): bilinear resize of the
+    [1,1,N,E] table along the sequence axis when seq_len != num_embeddings."""
+    pe = sd[prefix + ".pos_embed.pos_embed"]
+    n, e = pe.shape[2], pe.shape[3]
+    if seq_len != n:
+        pe = F.interpolate(pe, size=(seq_len, e), mode="bilinear")
+    return pe.reshape(1, seq_len, e)
+
+
+def vit_forward(sd: Dict[str, Tensor], x: Tensor, mode: str = "tiny", training: bool = True,
+                bn_state: Optional[BNState] = None) -> Tensor:
+    """VisionTransformer.forward -> forward_classifier -> extract_features -> _features_from_transformer ->
+    extract_patch_embeddings (vit.py:480-610), dropout p = 0, default (batch-first) MHA."""
+    e, n_layers, heads = VIT_CFG[mode]
+    y = conv_bn_act(sd, "patch_emb.0", x, stride=4, training=training, bn_state=bn_state, act="gelu")
+    y = conv_bn_act(sd, "patch_emb.1", y, stride=2, training=training, bn_state=bn_state, act="gelu")
+    y = conv_bn_act(sd, "patch_emb.2", y, stride=2, use_norm=False, use_act=False)
+    b = y.shape[0]
+    t = y.flatten(2).transpose(1, 2).contiguous()
+    t = positional_embedding(sd, "pos_embed", t.shape[1]).to(t.dtype) + t
+    t = torch.cat((sd["cls_token"].expand(b, -1, -1), t), dim=1)
+    for i in range(n_layers):
+        t = transformer_encoder(sd, f"transformer.{i}", t, heads, act="gelu", ln_eps=1e-6)
+    t = F.layer_norm(t, (e,), sd["post_transformer_norm.weight"], sd["post_transformer_norm.bias"], 1e-6)
+    return F.linear(t[:, 0], sd["classifier.weight"], sd["classifier.bias"])
+
+
+def generic_train_step(forward_fn, sd: Dict[str, Tensor], x: Tensor, y: Tensor, label_smoothing: float = 0.1, **kw):
+    """fwd + label-smoothed CE + bwd for any of the functional models above; returns (logits, loss, grads, BN running stats)."""
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    st = BNState()
+    logits = forward_fn(params, x, training=True, bn_state=st, **kw)
+    loss = cross_entropy(logits, y, label_smoothing)
+    names = [k for k, v in params.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(params[k]) for g, k in zip(grads, names)]
     return logits.detach(), loss.detach(), dict(zip(names, grads)), st.running

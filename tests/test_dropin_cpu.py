@@ -76,3 +76,39 @@ def test_reference_attribute_contract(ref_model):
     for attr in ("block", "in_channels", "out_channels", "stride", "groups", "kernel_size", "bias", "dilation"):
         assert hasattr(conv, attr), attr
     assert [n for n, _ in conv.block.named_children()] == ["conv", "norm", "act"]
+
+
+def test_vit_class_swap(ref_model):
+    """the reference's ViT builder -> class swap -> same tree / state_dict as cvnets_amd.build_vit."""
+    import yaml
+    import cvnets
+    import cvnets_amd
+    from cvnets_amd import dropin
+    from options.utils import flatten_yaml_as_dict
+
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+        opts = parser.parse_args([])
+        cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/classification/imagenet/vit.yaml")))
+        for k, v in cfg.items():
+            if hasattr(opts, k):
+                setattr(opts, k, v)
+        setattr(opts, "dataset.category", "classification")
+        setattr(opts, "dev.device", "cpu")
+        setattr(opts, "model.classification.gradient_checkpointing", False)
+        model = cvnets.get_model(opts)
+    finally:
+        os.chdir(cwd)
+    names_before = [n for n, _ in model.named_modules()]
+    keys_before = list(model.state_dict().keys())
+    counts, left = dropin.swap_to_hip(model, strict=True)
+    assert left == []
+    assert counts["VisionTransformer"] == 1 and counts["TransformerEncoder"] == 12 and counts["ConvLayer2d"] == 3
+    ours = cvnets_amd.VisionTransformer(opts)
+    assert [n for n, _ in ours.named_modules()] == names_before
+    assert list(ours.state_dict().keys()) == keys_before == list(json.load(open(os.path.join(REPO, "tests", "golden", "vit_tiny_keys.json"))).keys())
+    assert ours.emb_dropout.p == model.emb_dropout.p
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 64, 64))

@@ -39,6 +39,29 @@ def test_oracle_matches_reference_fixture(name, mode, batch, res):
             assert np.allclose(running[key[4:]].numpy(), gold[key], rtol=1e-5, atol=1e-6), key
 
 
+@pytest.mark.parametrize("name,res", [("vit_tiny_64_b2", 64), ("vit_tiny_224_b2", 224)])
+def test_vit_oracle_matches_reference_fixture(name, res):
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    shapes = json.load(open(os.path.join(GOLD, "vit_tiny_keys.json")))
+    sd = seeded_state_dict(shapes, seed=0)
+    sd["cls_token"] = 0.02 * seeded_state_dict({"cls_token_values": (1, 1, 192)}, seed=0)["cls_token_values"]
+    x = seeded_input((2, 3, res, res), seed=1)
+    y = seeded_labels(2, 1000, seed=1)
+    assert np.allclose(orc.vit_forward(sd, x, mode="tiny", training=False).numpy(), gold["logits_eval"], rtol=1e-4, atol=1e-5)
+    logits, loss, grads, running = orc.generic_train_step(orc.vit_forward, sd, x, y, mode="tiny")
+    assert np.allclose(logits.numpy(), gold["logits_train"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5
+    names = [str(n) for n in gold["grad_names"]]
+    assert sorted(names) == sorted(grads.keys())
+    assert np.allclose(np.array([grads[k].norm().item() for k in names]), gold["grad_norm"], rtol=1e-3, atol=1e-7)
+    for key in gold.files:
+        if key.startswith("grad::"):
+            assert np.allclose(grads[key[6:]].numpy(), gold[key], rtol=1e-3, atol=1e-6), key
+        if key.startswith("bn::"):
+            assert np.allclose(running[key[4:]].numpy(), gold[key], rtol=1e-5, atol=1e-6), key
+
+
 def test_oracle_mha_matches_reference_fixture():
     gold = np.load(os.path.join(GOLD, "mha_cases.npz"))
     for idx in range(4):

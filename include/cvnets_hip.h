@@ -118,10 +118,29 @@ int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const u
 int cvh_seed_advance(unsigned long long* seed, void* stream);
 int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void* stream);
 
-/* F.interpolate(mode="bilinear", align_corners=False) of MobileViTBlock.unfolding/folding for feature maps that are not a
- * multiple of the patch (cvnets/modules/mobilevit_block.py:191-200, 260-266); bwd = exact adjoint (gather form). */
-int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, void* stream);
-int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, void* stream);
+/* F.interpolate(mode="bilinear") for feature maps that are not a multiple of the patch: align_corners=False in
+ * MobileViTBlock.unfolding/folding (cvnets/modules/mobilevit_block.py:191-200, 260-266), align_corners=True in
+ * MobileViTBlockv2.resize_input_if_needed (:595-603); bwd = exact adjoint (gather form). */
+int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream);
+int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream);
+
+/* ---- MobileViTv2: GroupNorm(1) ("layer_norm_2d") and linear self-attention ------------------------------ */
+/* LayerNorm2D_NCHW = nn.GroupNorm(num_groups=1) (cvnets/layers/normalization/layer_norm.py:75-108) on an NHWC map [B][HW][C]:
+ * per-sample statistics over HW*C, per-channel affine.  stats[B][2] = (mean, rstd) is written by fwd and read by bwd;
+ * part is scratch of B * cvh_gn_chunks() * 2 floats (fwd) / B * cvh_gn_chunks() * 2*C floats (bwd: per-chunk column sums of
+ * dy and dy*xhat — reduce over its B*chunks rows (cvh_sum_partials) for dbeta [0,C) / dgamma [C,2C)); coeff is B*2 scratch. */
+int cvh_gn_chunks(int B, int HW, int C);
+int cvh_gn_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, float* part, int B, int HW, int C,
+               float eps, void* stream);
+int cvh_gn_bwd(int dtype, const void* x, const void* dy, const float* stats, const float* gamma, void* dx, float* part, float* coeff, int B,
+               int HW, int C, void* stream);
+/* LinearSelfAttention._forward_self_attn (cvnets/layers/linear_attention.py:147-162) on the un-unfolded map: kvq is the
+ * qkv_proj output [B*H*W][2C+8] = key | value | query | 7 zero columns; pixels (h, w) with equal (h % ph, w % pw) form the
+ * reference's [b, :, p, :] slice of F.unfold (cvnets/modules/mobilevit_block.py:526-540).  out[B*H*W][C] = relu(value) *
+ * sum_n softmax_n(query) * key; cv[B*ph*pw][C] (the context vectors) is saved for bwd.  bwd writes dkvq in the same layout. */
+int cvh_linattn_fwd(int dtype, const void* kvq, void* out, float* cv, int B, int H, int W, int ph, int pw, int C, void* stream);
+int cvh_linattn_bwd(int dtype, const void* kvq, const float* cv, const void* dout, void* dkvq, int B, int H, int W, int ph, int pw, int C,
+                    void* stream);
 
 /* ---- token plumbing for ViT / CLIP --------------------------------------------------------------- */
 /* out[b][0] = cls, out[b][1+n] = patch[b][n] + pos[n]  (cls == NULL: no class token).  VisionTransformer.extract_patch_embeddings,

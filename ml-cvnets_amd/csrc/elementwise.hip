@@ -483,8 +483,13 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
 // multiple of the patch: cvnets/modules/mobilevit_block.py:191-200, 260-266).  Same arithmetic as ATen's
 // upsample_bilinear2d: src = scale*(dst+0.5)-0.5 clamped at 0, i1 = min(i0+1, in-1).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bilin_src(int o, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
-  float s = scale * ((float)o + 0.5f) - 0.5f;
+__device__ __forceinline__ float resize_scale(int in_size, int out_size, int align) {
+  if (align) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  return (float)in_size / (float)out_size;
+}
+// align_corners: src = dst * (in-1)/(out-1)  (MobileViTBlockv2.resize_input_if_needed, mobilevit_block.py:595-603).
+__device__ __forceinline__ void bilin_src(int o, float scale, int in_size, int align, int& i0, int& i1, float& l0, float& l1) {
+  float s = align ? scale * (float)o : scale * ((float)o + 0.5f) - 0.5f;
   if (s < 0.f) s = 0.f;
   i0 = (int)s;
   if (i0 > in_size - 1) i0 = in_size - 1;
@@ -494,10 +499,10 @@ __device__ __forceinline__ void bilin_src(int o, float scale, int in_size, int& 
 }
 
 template <typename T>
-__global__ void resize_bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int Ho, int Wo, int C) {
+__global__ void resize_bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int Ho, int Wo, int C, int align) {
   const int cgs = C / 8;
   const size_t total = (size_t)B * Ho * Wo * cgs;
-  const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  const float sh = resize_scale(H, Ho, align), sw = resize_scale(W, Wo, align);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cg = (int)(idx % cgs);
     size_t t = idx / cgs;
@@ -507,8 +512,8 @@ __global__ void resize_bilinear_fwd_kernel(const T* __restrict__ x, T* __restric
     const size_t b = t / Ho;
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
-    bilin_src(oy, sh, H, y0, y1, ly0, ly1);
-    bilin_src(ox, sw, W, x0, x1, lx0, lx1);
+    bilin_src(oy, sh, H, align, y0, y1, ly0, ly1);
+    bilin_src(ox, sw, W, align, x0, x1, lx0, lx1);
     float p00[8], p01[8], p10[8], p11[8], o[8];
     v8_unpack(v8_load<T>(x + ((b * H + y0) * W + x0) * C + cg * 8), p00);
     v8_unpack(v8_load<T>(x + ((b * H + y0) * W + x1) * C + cg * 8), p01);
@@ -524,10 +529,10 @@ __global__ void resize_bilinear_fwd_kernel(const T* __restrict__ x, T* __restric
 
 // gather-form backward: every input pixel sums the output pixels that sampled it (deterministic, no atomics)
 template <typename T>
-__global__ void resize_bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int Ho, int Wo, int C) {
+__global__ void resize_bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int Ho, int Wo, int C, int align) {
   const int cgs = C / 8;
   const size_t total = (size_t)B * H * W * cgs;
-  const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  const float sh = resize_scale(H, Ho, align), sw = resize_scale(W, Wo, align);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int cg = (int)(idx % cgs);
     size_t t = idx / cgs;
@@ -535,21 +540,27 @@ __global__ void resize_bilinear_bwd_kernel(const T* __restrict__ dy, T* __restri
     t /= W;
     const int iy = (int)(t % H);
     const size_t b = t / H;
-    int oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
-    int ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    int oy_lo, oy_hi, ox_lo, ox_hi;  // conservative window of output pixels whose two taps can include (iy, ix)
+    if (align) {
+      oy_lo = sh > 0.f ? (int)floorf(((float)iy - 1.f) / sh) - 1 : 0; oy_hi = sh > 0.f ? (int)ceilf(((float)iy + 1.f) / sh) + 1 : Ho - 1;
+      ox_lo = sw > 0.f ? (int)floorf(((float)ix - 1.f) / sw) - 1 : 0; ox_hi = sw > 0.f ? (int)ceilf(((float)ix + 1.f) / sw) + 1 : Wo - 1;
+    } else {
+      oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1; oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
+      ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1; ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    }
     oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
     ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1;
       float ly0, ly1;
-      bilin_src(oy, sh, H, y0, y1, ly0, ly1);
+      bilin_src(oy, sh, H, align, y0, y1, ly0, ly1);
       const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
       if (wy == 0.f) continue;
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
         int x0, x1;
         float lx0, lx1;
-        bilin_src(ox, sw, W, x0, x1, lx0, lx1);
+        bilin_src(ox, sw, W, align, x0, x1, lx0, lx1);
         const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
         if (wx == 0.f) continue;
         float d[8];
@@ -734,18 +745,18 @@ extern "C" int cvh_seed_advance(unsigned long long* seed, void* stream) {
   return 0;
 }
 
-extern "C" int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, void* stream) {
+extern "C" int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream) {
   if (C % 8) return -2;
   size_t total = (size_t)B * Ho * Wo * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_bilinear_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, Ho, Wo, C);)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_bilinear_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, Ho, Wo, C, align_corners);)
   CVH_CHECK_LAUNCH();
   return 0;
 }
 /* dx[B][H][W][C] = adjoint of the (H,W)->(Ho,Wo) resize applied to dy[B][Ho][Wo][C] */
-extern "C" int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, void* stream) {
+extern "C" int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream) {
   if (C % 8) return -2;
   size_t total = (size_t)B * H * W * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_bilinear_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, H, W, Ho, Wo, C);)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_bilinear_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, B, H, W, Ho, Wo, C, align_corners);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -51,8 +51,13 @@ SIGNATURES = {
     "cvh_dropout": [I, P, P, L, F, P, U, P],
     "cvh_seed_advance": [P, P],
     "cvh_add": [I, P, P, P, L, P],
-    "cvh_resize_bilinear_fwd": [I, P, P, I, I, I, I, I, I, P],
-    "cvh_resize_bilinear_bwd": [I, P, P, I, I, I, I, I, I, P],
+    "cvh_gn_chunks": [I, I, I],
+    "cvh_gn_fwd": [I, P, P, P, P, P, P, I, I, I, F, P],
+    "cvh_gn_bwd": [I, P, P, P, P, P, P, P, I, I, I, P],
+    "cvh_linattn_fwd": [I, P, P, P, I, I, I, I, I, I, P],
+    "cvh_linattn_bwd": [I, P, P, P, P, I, I, I, I, I, I, P],
+    "cvh_resize_bilinear_fwd": [I, P, P, I, I, I, I, I, I, I, P],
+    "cvh_resize_bilinear_bwd": [I, P, P, I, I, I, I, I, I, I, P],
     "cvh_layernorm_fwd": [I, P, P, P, P, P, P, L, I, F, P],
     "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
     "cvh_ln_bwd_rows": [L],

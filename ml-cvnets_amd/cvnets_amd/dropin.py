@@ -36,6 +36,11 @@ _BY_NAME = {
     "VisionTransformer": models.VisionTransformer,
     "PositionalEmbedding": layers.PositionalEmbedding,
     "LearnablePositionalEmbedding": layers.LearnablePositionalEmbedding,
+    "LayerNorm2D_NCHW": layers.LayerNorm2D_NCHW,
+    "LinearSelfAttention": layers.LinearSelfAttention,
+    "LinearAttnFFN": modules.LinearAttnFFN,
+    "MobileViTBlockv2": modules.MobileViTBlockv2,
+    "MobileViTv2": models.MobileViTv2,
 }
 
 

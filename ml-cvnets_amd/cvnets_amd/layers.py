@@ -53,6 +53,11 @@ def default_opts(**overrides) -> argparse.Namespace:
         "model.classification.vit.stochastic_dropout": 0.0,
         "model.classification.vit.sinusoidal_pos_emb": False,
         "model.classification.vit.use_pytorch_mha": False,
+        "model.classification.mitv2.width_multiplier": 1.0,
+        "model.classification.mitv2.attn_dropout": 0.0,
+        "model.classification.mitv2.ffn_dropout": 0.0,
+        "model.classification.mitv2.dropout": 0.0,
+        "model.classification.mitv2.attn_norm_layer": "layer_norm_2d",
     }
     base.update(overrides)
     for k, v in base.items():
@@ -136,7 +141,24 @@ class LayerNorm(nn.LayerNorm):
         return y.view(shp)
 
 
-NORM_LAYER_REGISTRY = {"batch_norm": BatchNorm2d, "batch_norm_2d": BatchNorm2d, "layer_norm": LayerNorm}
+class LayerNorm2D_NCHW(nn.GroupNorm):
+    """cvnets/layers/normalization/layer_norm.py:75-108: nn.GroupNorm(num_groups=1) — statistics over (C, H, W) of each sample."""
+
+    def __init__(self, num_features: int, eps: Optional[float] = 1e-5, elementwise_affine: Optional[bool] = True, *args, **kwargs) -> None:
+        super().__init__(num_channels=num_features, eps=eps, affine=elementwise_affine, num_groups=1)
+        self.num_channels = num_features
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.dim() != 4 or not self.affine:
+            raise NotImplementedError("layer_norm_2d is on the HIP hot path for affine 4-D maps only")
+        return ops.group_norm1(ops.to_nhwc(x), self.weight, self.bias, self.eps)
+
+    def __repr__(self):
+        return "{}(num_channels={}, eps={}, affine={})".format(self.__class__.__name__, self.num_channels, self.eps, self.affine)
+
+
+NORM_LAYER_REGISTRY = {"batch_norm": BatchNorm2d, "batch_norm_2d": BatchNorm2d, "layer_norm": LayerNorm,
+                       "layer_norm_2d": LayerNorm2D_NCHW, "layer_norm_nchw": LayerNorm2D_NCHW}
 
 
 def get_normalization_layer(opts, num_features: int, norm_type: Optional[str] = None, num_groups: Optional[int] = None, *args, **kwargs):
@@ -376,6 +398,45 @@ class PositionalEmbedding(nn.Module):
 
     def __repr__(self):
         return self.pos_embed.__repr__()
+
+
+# ---------------------------------------------------------------------------------------------
+# linear self-attention  (cvnets/layers/linear_attention.py:15-215)
+# ---------------------------------------------------------------------------------------------
+class LinearSelfAttention(nn.Module):
+    """MobileViTv2 separable self-attention.  ``forward(x)`` takes the FEATURE MAP [B, C, H, W] (NHWC strides), not the unfolded
+    [B, C, P, N] tensor of the reference: pixels with equal (h % patch_h, w % patch_w) are the reference's dim-2 slice, the
+    softmax / context sum run over the patches inside the kernel (csrc/linattn.hip), so unfold / fold never materialise.
+    qkv_proj's weight rows are consumed in the order key | value | query | 7 zero rows (a 16-byte aligned GEMM output);
+    the permutation is an autograd-visible torch.cat of the [1+2C, C] parameter, so its gradient lands in reference order."""
+
+    def __init__(self, opts, embed_dim: int, attn_dropout: Optional[float] = 0.0, bias: Optional[bool] = True, *args, **kwargs) -> None:
+        super().__init__()
+        self.qkv_proj = ConvLayer2d(opts=opts, in_channels=embed_dim, out_channels=1 + (2 * embed_dim), bias=bias, kernel_size=1,
+                                    use_norm=False, use_act=False)
+        self.qkv_proj.block.conv._cvh_skip_pack = True
+        self.attn_dropout = Dropout(p=attn_dropout)
+        self.out_proj = ConvLayer2d(opts=opts, in_channels=embed_dim, out_channels=embed_dim, bias=bias, kernel_size=1, use_norm=False,
+                                    use_act=False)
+        self.embed_dim = embed_dim
+
+    def __repr__(self):
+        return "{}(embed_dim={}, attn_dropout={})".format(self.__class__.__name__, self.embed_dim, self.attn_dropout.p)
+
+    def forward(self, x: Tensor, x_prev: Optional[Tensor] = None, patch_hw: Tuple[int, int] = (2, 2), residual: Optional[Tensor] = None,
+                *args, **kwargs) -> Tensor:
+        if x_prev is not None:
+            raise NotImplementedError("linear cross-attention (x_prev) is not on the HIP hot path")
+        if self.attn_dropout.p > 0.0 and self.training:
+            raise NotImplementedError("dropout on the context scores is not on the HIP hot path (mitv2.attn_dropout defaults to 0)")
+        C = self.embed_dim
+        conv = self.qkv_proj.block.conv
+        w, b = conv.weight, conv.bias
+        wp = torch.cat((w[1:], w[:1], w.new_zeros((7,) + tuple(w.shape[1:]))), dim=0)  # plumbing: [2C+8, C, 1, 1] row permutation
+        bp = torch.cat((b[1:], b[:1], b.new_zeros(7)), dim=0) if b is not None else None
+        kvq = ops.conv_bn_act(ops.to_nhwc(x), wp, bp)
+        out = ops.linear_attention(kvq, C, patch_hw[0], patch_hw[1])
+        return self.out_proj(out, residual=residual)
 
 
 # ---------------------------------------------------------------------------------------------

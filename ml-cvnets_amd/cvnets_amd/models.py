@@ -11,7 +11,7 @@ from torch import Tensor, nn
 
 from . import ops
 from .layers import ConvLayer2d, Dropout, GlobalPool, LinearLayer, opt
-from .modules import InvertedResidual, MobileViTBlock
+from .modules import InvertedResidual, MobileViTBlock, MobileViTBlockv2, make_divisible
 
 
 def get_configuration(opts) -> Dict:
@@ -244,3 +244,95 @@ def build_vit(mode: str = "tiny", opts=None, **overrides) -> VisionTransformer:
         base.update(overrides)
         opts = default_opts(**base)
     return VisionTransformer(opts)
+
+
+# =============================================================================================
+# MobileViTv2  (cvnets/models/classification/mobilevit_v2.py:20-226, config/mobilevit_v2.py:11-77)
+# =============================================================================================
+def get_mitv2_configuration(opts) -> Dict:
+    wm = opt(opts, "model.classification.mitv2.width_multiplier", 1.0)
+    ffn_multiplier, mv2_exp_mult = 2, 2
+    layer_0_dim = int(make_divisible(max(16, min(64, 32 * wm)), divisor=8, min_value=16))
+    cfg = {
+        "layer0": {"img_channels": 3, "out_channels": layer_0_dim},
+        "layer1": {"out_channels": int(make_divisible(64 * wm, divisor=16)), "expand_ratio": mv2_exp_mult, "num_blocks": 1, "stride": 1,
+                   "block_type": "mv2"},
+        "layer2": {"out_channels": int(make_divisible(128 * wm, divisor=8)), "expand_ratio": mv2_exp_mult, "num_blocks": 2, "stride": 2,
+                   "block_type": "mv2"},
+        "last_layer_exp_factor": 4,
+    }
+    for name, out, attn, nblk in (("layer3", 256, 128, 2), ("layer4", 384, 192, 4), ("layer5", 512, 256, 3)):
+        cfg[name] = {"out_channels": int(make_divisible(out * wm, divisor=8)), "attn_unit_dim": int(make_divisible(attn * wm, divisor=8)),
+                     "ffn_multiplier": ffn_multiplier, "attn_blocks": nblk, "patch_h": 2, "patch_w": 2, "stride": 2,
+                     "mv_expand_ratio": mv2_exp_mult, "block_type": "mobilevit"}
+    return cfg
+
+
+class MobileViTv2(nn.Module):
+    def __init__(self, opts, *args, **kwargs) -> None:
+        super().__init__()
+        num_classes = opt(opts, "model.classification.n_classes", 1000)
+        pool_type = opt(opts, "model.layer.global_pool", "mean")
+        cfg = get_mitv2_configuration(opts)
+        image_channels, out_channels = cfg["layer0"]["img_channels"], cfg["layer0"]["out_channels"]
+        self.dilation = 1
+        self.model_conf_dict = dict()
+        self.conv_1 = ConvLayer2d(opts=opts, in_channels=image_channels, out_channels=out_channels, kernel_size=3, stride=2, use_norm=True,
+                                  use_act=True)
+        self.model_conf_dict["conv1"] = {"in": image_channels, "out": out_channels}
+        in_channels = out_channels
+        for idx in range(1, 6):
+            layer, out_channels = self._make_layer(opts=opts, input_channel=in_channels, cfg=cfg[f"layer{idx}"])
+            setattr(self, f"layer_{idx}", layer)
+            self.model_conf_dict[f"layer{idx}"] = {"in": in_channels, "out": out_channels}
+            in_channels = out_channels
+        from .layers import Identity
+
+        self.conv_1x1_exp = Identity()
+        self.model_conf_dict["exp_before_cls"] = {"in": out_channels, "out": out_channels}
+        self.classifier = nn.Sequential(GlobalPool(pool_type=pool_type, keep_dim=False),
+                                        LinearLayer(in_features=out_channels, out_features=num_classes, bias=True))
+        self.n_classes = num_classes
+
+    def _make_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+        if cfg.get("block_type", "mobilevit").lower() == "mobilevit":
+            return self._make_mit_layer(opts, input_channel, cfg)
+        return MobileViT._make_mobilenet_layer(opts, input_channel, cfg)
+
+    def _make_mit_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+        block = []
+        if cfg.get("stride", 1) == 2:
+            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=cfg.get("out_channels"), stride=2,
+                                          expand_ratio=cfg.get("mv_expand_ratio", 4), dilation=self.dilation))
+            input_channel = cfg.get("out_channels")
+        block.append(MobileViTBlockv2(
+            opts=opts, in_channels=input_channel, attn_unit_dim=cfg["attn_unit_dim"], ffn_multiplier=cfg.get("ffn_multiplier"),
+            n_attn_blocks=cfg.get("attn_blocks", 1), patch_h=cfg.get("patch_h", 2), patch_w=cfg.get("patch_w", 2),
+            dropout=opt(opts, "model.classification.mitv2.dropout", 0.0), ffn_dropout=opt(opts, "model.classification.mitv2.ffn_dropout", 0.0),
+            attn_dropout=opt(opts, "model.classification.mitv2.attn_dropout", 0.0), conv_ksize=3,
+            attn_norm_layer=opt(opts, "model.classification.mitv2.attn_norm_layer", "layer_norm_2d"), dilation=self.dilation))
+        return nn.Sequential(*block), input_channel
+
+    def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
+        if self.training:
+            ops.advance_dropout_seed(x.device)
+            ops.pack_all(self)
+        x = ops.to_nhwc(x)
+        x = self.conv_1(x)
+        for idx in range(1, 6):
+            x = getattr(self, f"layer_{idx}")(x)
+        return self.conv_1x1_exp(x)
+
+    def forward_classifier(self, x: Tensor, *args, **kwargs) -> Tensor:
+        return self.classifier(self.extract_features(x))
+
+    def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
+        return self.forward_classifier(x, *args, **kwargs)
+
+
+def build_mobilevit_v2(width_multiplier: float = 1.0, opts=None, **overrides) -> MobileViTv2:
+    from .layers import default_opts
+
+    if opts is None:
+        opts = default_opts(**{"model.classification.mitv2.width_multiplier": width_multiplier}, **overrides)
+    return MobileViTv2(opts)

@@ -10,8 +10,8 @@ import torch
 from torch import Tensor, nn
 
 from . import ops
-from .layers import (ConvLayer2d, Dropout, Identity, LayerNorm, LinearLayer, MultiHeadAttention, act_code, build_activation_layer,
-                     get_normalization_layer, opt)
+from .layers import (ConvLayer2d, Dropout, Identity, LayerNorm, LinearLayer, LinearSelfAttention, MultiHeadAttention, act_code,
+                     build_activation_layer, get_normalization_layer, opt)
 
 
 def make_divisible(v: Union[float, int], divisor: Optional[int] = 8, min_value: Optional[Union[float, int]] = None) -> Union[float, int]:
@@ -224,3 +224,137 @@ class MobileViTBlock(nn.Module):
         if isinstance(x, Tensor):
             return self.forward_spatial(x)
         raise NotImplementedError
+
+
+# =============================================================================================
+# MobileViTv2  (cvnets/modules/transformer.py:159-264 LinearAttnFFN, cvnets/modules/mobilevit_block.py:329-668 MobileViTBlockv2)
+# =============================================================================================
+class LinearAttnFFN(nn.Module):
+    """pre-norm linear-attention + conv-FFN block.  Runs on the feature map [B, C, H, W]: GroupNorm(1), the 1x1 convs and the
+    residuals are position-wise, and the attention kernel addresses the patch groups by stride (see LinearSelfAttention)."""
+
+    def __init__(self, opts, embed_dim: int, ffn_latent_dim: int, attn_dropout: Optional[float] = 0.0, dropout: Optional[float] = 0.1,
+                 ffn_dropout: Optional[float] = 0.0, norm_layer: Optional[str] = "layer_norm_2d", *args, **kwargs) -> None:
+        super().__init__()
+        attn_unit = LinearSelfAttention(opts, embed_dim=embed_dim, attn_dropout=attn_dropout, bias=True)
+        self.pre_norm_attn = nn.Sequential(
+            get_normalization_layer(opts=opts, norm_type=norm_layer, num_features=embed_dim),
+            attn_unit,
+            Dropout(p=dropout),
+        )
+        self.pre_norm_ffn = nn.Sequential(
+            get_normalization_layer(opts=opts, norm_type=norm_layer, num_features=embed_dim),
+            ConvLayer2d(opts=opts, in_channels=embed_dim, out_channels=ffn_latent_dim, kernel_size=1, stride=1, bias=True, use_norm=False,
+                        use_act=True),
+            Dropout(p=ffn_dropout),
+            ConvLayer2d(opts=opts, in_channels=ffn_latent_dim, out_channels=embed_dim, kernel_size=1, stride=1, bias=True, use_norm=False,
+                        use_act=False),
+            Dropout(p=dropout),
+        )
+        self.embed_dim = embed_dim
+        self.ffn_dim = ffn_latent_dim
+        self.ffn_dropout = ffn_dropout
+        self.std_dropout = dropout
+        self.attn_fn_name = attn_unit.__repr__()
+        self.norm_name = norm_layer
+
+    def __repr__(self) -> str:
+        return "{}(embed_dim={}, ffn_dim={}, dropout={}, ffn_dropout={}, attn_fn={}, norm_layer={})".format(
+            self.__class__.__name__, self.embed_dim, self.ffn_dim, self.std_dropout, self.ffn_dropout, self.attn_fn_name, self.norm_name)
+
+    def forward(self, x: Tensor, x_prev: Optional[Tensor] = None, patch_hw: Tuple[int, int] = (2, 2), *args, **kwargs) -> Tensor:
+        if x_prev is not None:
+            raise NotImplementedError("linear cross-attention (x_prev) is not on the HIP hot path")
+        x = ops.to_nhwc(x)
+        norm, attn, drop = self.pre_norm_attn[0], self.pre_norm_attn[1], self.pre_norm_attn[2]
+        droppy = self.training and drop.p > 0.0
+        y = attn(norm(x), patch_hw=patch_hw, residual=None if droppy else x)  # residual rides in out_proj's GEMM epilogue
+        x = ops.add(x, drop(y)) if droppy else y
+        norm, fc1, drop1, fc2, drop2 = (self.pre_norm_ffn[i] for i in range(5))
+        h = drop1(fc1(norm(x)))
+        droppy = self.training and drop2.p > 0.0
+        y = fc2(h, residual=None if droppy else x)
+        return ops.add(x, drop2(y)) if droppy else y
+
+
+class MobileViTBlockv2(nn.Module):
+    """local depthwise 3x3 + 1x1 -> n x LinearAttnFFN + GroupNorm(1) over patch groups -> 1x1 projection (BN)."""
+
+    def __init__(self, opts, in_channels: int, attn_unit_dim: int, ffn_multiplier=2.0, n_attn_blocks: Optional[int] = 2,
+                 attn_dropout: Optional[float] = 0.0, dropout: Optional[float] = 0.0, ffn_dropout: Optional[float] = 0.0,
+                 patch_h: Optional[int] = 8, patch_w: Optional[int] = 8, conv_ksize: Optional[int] = 3, dilation: Optional[int] = 1,
+                 attn_norm_layer: Optional[str] = "layer_norm_2d", *args, **kwargs) -> None:
+        super().__init__()
+        cnn_out_dim = attn_unit_dim
+        conv_3x3_in = ConvLayer2d(opts=opts, in_channels=in_channels, out_channels=in_channels, kernel_size=conv_ksize, stride=1,
+                                  use_norm=True, use_act=True, dilation=dilation, groups=in_channels)
+        conv_1x1_in = ConvLayer2d(opts=opts, in_channels=in_channels, out_channels=cnn_out_dim, kernel_size=1, stride=1, use_norm=False,
+                                  use_act=False)
+        self.local_rep = nn.Sequential(conv_3x3_in, conv_1x1_in)
+        self.global_rep, attn_unit_dim = self._build_attn_layer(opts=opts, d_model=attn_unit_dim, ffn_mult=ffn_multiplier,
+                                                                n_layers=n_attn_blocks, attn_dropout=attn_dropout, dropout=dropout,
+                                                                ffn_dropout=ffn_dropout, attn_norm_layer=attn_norm_layer)
+        self.conv_proj = ConvLayer2d(opts=opts, in_channels=cnn_out_dim, out_channels=in_channels, kernel_size=1, stride=1, use_norm=True,
+                                     use_act=False)
+        self.patch_h = patch_h
+        self.patch_w = patch_w
+        self.patch_area = self.patch_w * self.patch_h
+        self.cnn_in_dim = in_channels
+        self.cnn_out_dim = cnn_out_dim
+        self.transformer_in_dim = attn_unit_dim
+        self.dropout = dropout
+        self.attn_dropout = attn_dropout
+        self.ffn_dropout = ffn_dropout
+        self.n_blocks = n_attn_blocks
+        self.conv_ksize = conv_ksize
+        self.enable_coreml_compatible_fn = opt(opts, "common.enable_coreml_compatible_module", False)
+        if self.enable_coreml_compatible_fn:
+            raise NotImplementedError("the CoreML-compatible unfolding is an export path, not the HIP hot path")
+
+    def _build_attn_layer(self, opts, d_model: int, ffn_mult, n_layers: int, attn_dropout: float, dropout: float, ffn_dropout: float,
+                          attn_norm_layer: str, *args, **kwargs) -> Tuple[nn.Module, int]:
+        if isinstance(ffn_mult, (list, tuple)) and len(ffn_mult) == 2:
+            step = (ffn_mult[1] - ffn_mult[0]) / max(n_layers - 1, 1)
+            ffn_dims = [(ffn_mult[0] + step * i) * d_model for i in range(n_layers)]
+        elif isinstance(ffn_mult, (list, tuple)) and len(ffn_mult) == 1:
+            ffn_dims = [ffn_mult[0] * d_model] * n_layers
+        elif isinstance(ffn_mult, (int, float)):
+            ffn_dims = [ffn_mult * d_model] * n_layers
+        else:
+            raise NotImplementedError
+        ffn_dims = [int((d // 16) * 16) for d in ffn_dims]
+        global_rep = [LinearAttnFFN(opts=opts, embed_dim=d_model, ffn_latent_dim=ffn_dims[i], attn_dropout=attn_dropout, dropout=dropout,
+                                    ffn_dropout=ffn_dropout, norm_layer=attn_norm_layer) for i in range(n_layers)]
+        global_rep.append(get_normalization_layer(opts=opts, norm_type=attn_norm_layer, num_features=d_model))
+        return nn.Sequential(*global_rep), d_model
+
+    def __repr__(self) -> str:
+        s = "{}(".format(self.__class__.__name__) + "\n\t Local representations"
+        for m in self.local_rep:
+            s += "\n\t\t {}".format(m)
+        s += "\n\t Global representations with patch size of {}x{}".format(self.patch_h, self.patch_w)
+        for m in self.global_rep:
+            s += "\n\t\t {}".format(m)
+        s += "\n\t\t {}".format(self.conv_proj)
+        return s + "\n)"
+
+    def resize_input_if_needed(self, x: Tensor) -> Tensor:
+        B, C, H, W = x.shape
+        if H % self.patch_h != 0 or W % self.patch_w != 0:  # mobilevit_block.py:595-603 (align_corners=True)
+            nh = int(math.ceil(H / self.patch_h) * self.patch_h)
+            nw = int(math.ceil(W / self.patch_w) * self.patch_w)
+            x = ops.resize_bilinear(x, nh, nw, align_corners=True)
+        return x
+
+    def forward_spatial(self, x: Tensor, *args, **kwargs) -> Tensor:
+        x = self.resize_input_if_needed(ops.to_nhwc(x))
+        fm = self.local_rep(x)
+        phw = (self.patch_h, self.patch_w)
+        for layer in self.global_rep:  # F.unfold / F.fold of the reference (:526-555) are index arithmetic inside the attention kernel
+            fm = layer(fm, patch_hw=phw) if isinstance(layer, LinearAttnFFN) else layer(fm)
+        return self.conv_proj(fm)
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, tuple):
+            raise NotImplementedError("temporal (x, x_prev) MobileViTv2 blocks are not on the HIP hot path")
+        return self.forward_spatial(x)

@@ -188,6 +188,8 @@ class PackPlan:
         entries = []
         for m in module.modules():
             if isinstance(m, torch.nn.Conv2d):
+                if getattr(m, "_cvh_skip_pack", False):  # weight is consumed through a permuted copy (LinearSelfAttention.qkv_proj)
+                    continue
                 w = m.weight
                 if m.groups == 1:
                     entries.append((w, 0))
@@ -255,6 +257,8 @@ def set_inplace_param_grads(flag: bool) -> None:
 
 def _grad_sink(param: Optional[torch.Tensor]):
     if not _INPLACE_PARAM_GRADS or param is None:
+        return None
+    if not param.is_leaf:
         return None
     g = param.grad
     if g is None or g.dtype != torch.float32 or not g.is_contiguous():
@@ -706,6 +710,101 @@ def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, 
 # ------------------------------------------------------------------------------------------------
 # global average pool
 # ------------------------------------------------------------------------------------------------
+class AddFn(torch.autograd.Function):
+    """y = a + b for same-layout activations (residual adds that cannot ride in a GEMM epilogue, e.g. after a dropout)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _check_dev(a)
+        if a.shape != b.shape or a.stride() != b.stride() or a.dtype != b.dtype:
+            raise RuntimeError("add: operands must share shape, layout and dtype")
+        y = torch.empty_like(a)
+        _lib.call("cvh_add", _dt(a), _p(a), _p(b), _p(y), a.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class GroupNorm1Fn(torch.autograd.Function):
+    """nn.GroupNorm(num_groups=1) == LayerNorm2D_NCHW (cvnets/layers/normalization/layer_norm.py:75-108) on an NHWC map."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _check_dev(x)
+        B, C, H, W = x.shape
+        chunks = _lib.query("cvh_gn_chunks", B, H * W, C)
+        y = torch.empty_like(x)
+        stats = _f32(B * 2, x.device)
+        part = _f32(B * chunks * 2, x.device)
+        _lib.call("cvh_gn_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(part), B, H * W, C, float(eps), _stream())
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.params = (gamma, beta)
+        ctx.chunks = chunks
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dout = as_nhwc(dout)
+        chunks = ctx.chunks
+        part = _f32(B * chunks * 2 * C, x.device)
+        coeff = _f32(B * 2, x.device)
+        dx = torch.empty_like(x)
+        _lib.call("cvh_gn_bwd", _dt(x), _p(x), _p(dout), _p(stats), _p(gamma), _p(dx), _p(part), _p(coeff), B, H * W, C, _stream())
+        gp, bp = ctx.params
+        sg, sb = _grad_sink(gp), _grad_sink(bp)
+        if sg is not None and sb is not None:
+            _lib.call("cvh_sum_partials", _p(part), B * chunks, 2 * C, C, _p(sb), 1.0, 1, _stream())
+            _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, B * chunks, 2 * C, C, _p(sg), 1.0, 1, _stream())
+            return dx, None, None, None
+        dgb = _f32(2 * C, x.device)
+        _lib.call("cvh_sum_partials", _p(part), B * chunks, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())
+        return dx, dgb[C:], dgb[:C], None
+
+
+def group_norm1(x, gamma, beta, eps=1e-5):
+    return GroupNorm1Fn.apply(x, gamma, beta, float(eps))
+
+
+class LinearAttnFn(torch.autograd.Function):
+    """LinearSelfAttention core (cvnets/layers/linear_attention.py:147-162) between qkv_proj and out_proj, on the un-unfolded NHWC
+    map: kvq [B, 2C+8, H, W] (key | value | query | zero pad) -> relu(value) * context_vector [B, C, H, W]."""
+
+    @staticmethod
+    def forward(ctx, kvq, C, ph, pw):
+        _check_dev(kvq)
+        B, LD, H, W = kvq.shape
+        if LD != 2 * C + 8:
+            raise RuntimeError("kvq tensor must have 2C+8 channels")
+        out = nhwc_empty(B, C, H, W, kvq.dtype, kvq.device)
+        cv = _f32(B * ph * pw * C, kvq.device)
+        _lib.call("cvh_linattn_fwd", _dt(kvq), _p(kvq), _p(out), _p(cv), B, H, W, ph, pw, C, _stream())
+        ctx.save_for_backward(kvq, cv)
+        ctx.geom = (C, ph, pw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        kvq, cv = ctx.saved_tensors
+        C, ph, pw = ctx.geom
+        B, LD, H, W = kvq.shape
+        dout = as_nhwc(dout)
+        dkvq = torch.empty_like(kvq)
+        _lib.call("cvh_linattn_bwd", _dt(kvq), _p(kvq), _p(cv), _p(dout), _p(dkvq), B, H, W, ph, pw, C, _stream())
+        return dkvq, None, None, None
+
+
+def linear_attention(kvq, C: int, ph: int, pw: int):
+    return LinearAttnFn.apply(kvq, int(C), int(ph), int(pw))
+
+
 class GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -729,25 +828,25 @@ class ResizeBilinear(torch.autograd.Function):
     """F.interpolate(x, size, mode="bilinear", align_corners=False) on an NHWC map (mobilevit_block.py:191-200, 260-266)."""
 
     @staticmethod
-    def forward(ctx, x, Ho, Wo):
+    def forward(ctx, x, Ho, Wo, align):
         _check_dev(x)
         B, C, H, W = x.shape
         y = nhwc_empty(B, C, Ho, Wo, x.dtype, x.device)
-        _lib.call("cvh_resize_bilinear_fwd", _dt(x), _p(x), _p(y), B, H, W, Ho, Wo, C, _stream())
-        ctx.shape = (B, C, H, W, Ho, Wo)
+        _lib.call("cvh_resize_bilinear_fwd", _dt(x), _p(x), _p(y), B, H, W, Ho, Wo, C, align, _stream())
+        ctx.shape = (B, C, H, W, Ho, Wo, align)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, C, H, W, Ho, Wo = ctx.shape
+        B, C, H, W, Ho, Wo, align = ctx.shape
         dy = as_nhwc(dy)
         dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
-        _lib.call("cvh_resize_bilinear_bwd", _dt(dy), _p(dy), _p(dx), B, H, W, Ho, Wo, C, _stream())
-        return dx, None, None
+        _lib.call("cvh_resize_bilinear_bwd", _dt(dy), _p(dy), _p(dx), B, H, W, Ho, Wo, C, align, _stream())
+        return dx, None, None, None
 
 
-def resize_bilinear(x, Ho: int, Wo: int):
-    return ResizeBilinear.apply(x, int(Ho), int(Wo))
+def resize_bilinear(x, Ho: int, Wo: int, align_corners: bool = False):
+    return ResizeBilinear.apply(x, int(Ho), int(Wo), 1 if align_corners else 0)
 
 
 class VitEmbed(torch.autograd.Function):

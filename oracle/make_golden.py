@@ -252,6 +252,88 @@ def run_vit_case(name, mode, batch, res, outdir):
         json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
 
 
+V2_CASES = [("mobilevitv2_w050_64_b2", 0.5, 2, 64), ("mobilevitv2_w100_224_b2", 1.0, 2, 224), ("mobilevitv2_w075_96x160_b3", 0.75, 3, (96, 160))]
+V2_FULL_GRADS = ["conv_1.block.conv.weight", "layer_3.1.local_rep.0.block.conv.weight", "layer_3.1.global_rep.0.pre_norm_attn.0.weight",
+                 "layer_3.1.global_rep.0.pre_norm_attn.1.qkv_proj.block.conv.weight", "layer_3.1.global_rep.0.pre_norm_attn.1.qkv_proj.block.conv.bias",
+                 "layer_4.1.global_rep.3.pre_norm_ffn.1.block.conv.weight", "layer_5.1.global_rep.3.weight", "layer_5.1.conv_proj.block.norm.weight",
+                 "classifier.1.bias"]
+
+
+def build_reference_v2(wm: float):
+    os.chdir(REF)
+    import cvnets
+    from options.utils import flatten_yaml_as_dict
+
+    parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+    opts = parser.parse_args([])
+    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/classification/imagenet/mobilevit_v2.yaml")))
+    for k, v in cfg.items():
+        if hasattr(opts, k):
+            setattr(opts, k, v)
+    setattr(opts, "dataset.category", "classification")
+    setattr(opts, "dev.device", "cpu")
+    setattr(opts, "model.classification.mitv2.width_multiplier", wm)
+    return cvnets.get_model(opts)
+
+
+def run_v2_case(name, wm, batch, res, outdir):
+    torch.manual_seed(0)
+    model = build_reference_v2(wm)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)
+    hw = res if isinstance(res, tuple) else (res, res)
+    x = seeded_input((batch, 3) + hw, seed=1)
+    y = seeded_labels(batch, 1000, seed=1)
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(x).clone()
+    model.train()
+    logits = model(x)
+    loss = torch.nn.functional.cross_entropy(logits, y, label_smoothing=0.1)
+    model.zero_grad()
+    loss.backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    ref_sd_after = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lb = model(x)
+        loss_b = torch.nn.functional.cross_entropy(lb.float(), y, label_smoothing=0.1)
+    loss_b.backward()
+    gb = {k: p.grad.detach().clone().float() for k, p in model.named_parameters()}
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+    gmax = max(v.norm().item() for v in ref_grads.values())
+    bf16_ref = {"logits_train": rel(lb.detach().float(), logits.detach()), "loss": abs(float(loss_b.detach()) - float(loss.detach())),
+                "grad_global": (sum(float((gb[k].double() - ref_grads[k].double()).pow(2).sum()) for k in gb) /
+                                sum(float(ref_grads[k].double().pow(2).sum()) for k in gb)) ** 0.5,
+                "grad_norm_worst": max(abs(gb[k].norm().item() - ref_grads[k].norm().item()) / (ref_grads[k].norm().item() + 1e-3 * gmax) for k in gb),
+                "grad_full_worst": max(rel(gb[k], ref_grads[k]) for k in V2_FULL_GRADS)}
+    print(name, "reference bf16-autocast vs fp32:", {k: f"{v:.2e}" for k, v in bf16_ref.items()})
+    o_eval = orc.mobilevit_v2_forward(sd, x, width_multiplier=wm, training=False)
+    o_logits, o_loss, o_grads, o_running = orc.generic_train_step(orc.mobilevit_v2_forward, sd, x, y, width_multiplier=wm)
+    checks = {"logits_eval": rel(o_eval, logits_eval), "logits_train": rel(o_logits, logits.detach()), "loss": abs(float(o_loss) - float(loss.detach())),
+              "grad_worst_rel": max(rel(o_grads[k], ref_grads[k]) for k in ref_grads if ref_grads[k].norm() > 1e-6 * gmax),
+              "bn_running_worst_rel": max(rel(v, ref_sd_after[k]) for k, v in o_running.items())}
+    print(name, {k: f"{v:.2e}" for k, v in checks.items()})
+    assert checks["logits_eval"] < 1e-5 and checks["logits_train"] < 1e-5 and checks["loss"] < 1e-5, checks
+    assert checks["grad_worst_rel"] < 2e-4 and checks["bn_running_worst_rel"] < 1e-5, checks
+    names = list(ref_grads.keys())
+    out = {"logits_train": logits.detach().numpy(), "logits_eval": logits_eval.numpy(), "loss": np.float32(loss.item()),
+           "grad_names": np.array(names), "grad_norm": np.array([ref_grads[k].norm().item() for k in names], dtype=np.float64),
+           "oracle_vs_reference": np.array(json.dumps(checks)), "ref_bf16_autocast_err": np.array(json.dumps(bf16_ref))}
+    for k in V2_FULL_GRADS:
+        out["grad::" + k] = ref_grads[k].numpy()
+    for k in ("conv_1.block.norm.running_mean", "layer_4.1.conv_proj.block.norm.running_var"):
+        out["bn::" + k] = ref_sd_after[k].numpy()
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    with open(os.path.join(outdir, f"mobilevitv2_w{int(round(wm * 100)):03d}_keys.json"), "w") as f:
+        json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
+
+
 def mha_cases(outdir):
     """Pins oracle.multi_head_attention / transformer_encoder against the reference layer incl.
     masks (the only numerical cross-check the reference's own tests hold for this path:
@@ -298,4 +380,6 @@ if __name__ == "__main__":
         run_case(*c, outdir)
     for c in VIT_CASES:
         run_vit_case(*c, outdir)
+    for c in V2_CASES:
+        run_v2_case(*c, outdir)
     print("golden fixtures written to", outdir)

@@ -327,3 +327,79 @@ def generic_train_step(forward_fn, sd: Dict[str, Tensor], x: Tensor, y: Tensor, 
     grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
     grads = [g if g is not None else torch.zeros_like(params[k]) for g, k in zip(grads, names)]
     return logits.detach(), loss.detach(), dict(zip(names, grads)), st.running
+
+
+# --------------------------------------------------------------------------------------
+# MobileViTv2  (cvnets/models/classification/mobilevit_v2.py:20-226, config/mobilevit_v2.py:11-77)
+# --------------------------------------------------------------------------------------
+def mobilevit_v2_config(wm: float) -> Dict:
+    l0 = int(make_divisible(min(max(32 * wm, 16), 64), divisor=8, min_value=16))
+    return {"layer0": l0,
+            "layer1": dict(out=int(make_divisible(64 * wm, divisor=16)), blocks=1, stride=1),
+            "layer2": dict(out=int(make_divisible(128 * wm, divisor=8)), blocks=2, stride=2),
+            "layer3": dict(out=int(make_divisible(256 * wm, divisor=8)), attn=int(make_divisible(128 * wm, divisor=8)), nblk=2),
+            "layer4": dict(out=int(make_divisible(384 * wm, divisor=8)), attn=int(make_divisible(192 * wm, divisor=8)), nblk=4),
+            "layer5": dict(out=int(make_divisible(512 * wm, divisor=8)), attn=int(make_divisible(256 * wm, divisor=8)), nblk=3),
+            "exp": 2}
+
+
+def group_norm1(sd, prefix: str, x: Tensor, eps: float = 1e-5) -> Tensor:
+    """LayerNorm2D_NCHW = nn.GroupNorm(num_groups=1)  (cvnets/layers/normalization/layer_norm.py:75-108)."""
+    return F.group_norm(x, 1, sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def linear_self_attention(sd, prefix: str, x: Tensor) -> Tensor:
+    """LinearSelfAttention._forward_self_attn on the unfolded [B, C, P, N] tensor (cvnets/layers/linear_attention.py:147-162)."""
+    c = x.shape[1]
+    qkv = F.conv2d(x, sd[prefix + ".qkv_proj.block.conv.weight"], sd[prefix + ".qkv_proj.block.conv.bias"])
+    query, key, value = torch.split(qkv, [1, c, c], dim=1)
+    scores = F.softmax(query, dim=-1)
+    context = torch.sum(key * scores, dim=-1, keepdim=True)
+    out = F.relu(value) * context.expand_as(value)
+    return F.conv2d(out, sd[prefix + ".out_proj.block.conv.weight"], sd[prefix + ".out_proj.block.conv.bias"])
+
+
+def linear_attn_ffn(sd, prefix: str, x: Tensor) -> Tensor:
+    """LinearAttnFFN.forward, dropout p = 0  (cvnets/modules/transformer.py:248-264)."""
+    x = x + linear_self_attention(sd, prefix + ".pre_norm_attn.1", group_norm1(sd, prefix + ".pre_norm_attn.0", x))
+    y = group_norm1(sd, prefix + ".pre_norm_ffn.0", x)
+    y = F.silu(F.conv2d(y, sd[prefix + ".pre_norm_ffn.1.block.conv.weight"], sd[prefix + ".pre_norm_ffn.1.block.conv.bias"]))
+    y = F.conv2d(y, sd[prefix + ".pre_norm_ffn.3.block.conv.weight"], sd[prefix + ".pre_norm_ffn.3.block.conv.bias"])
+    return x + y
+
+
+def mobilevit_block_v2(sd, prefix: str, x: Tensor, n_blocks: int, training: bool, bn_state, ph: int = 2, pw: int = 2) -> Tensor:
+    """MobileViTBlockv2.forward_spatial with unfolding_pytorch / folding_pytorch (cvnets/modules/mobilevit_block.py:526-626)."""
+    b, c_in, h, w = x.shape
+    if h % ph != 0 or w % pw != 0:  # resize_input_if_needed (:595-603)
+        x = F.interpolate(x, size=(int(math.ceil(h / ph) * ph), int(math.ceil(w / pw) * pw)), mode="bilinear", align_corners=True)
+    fm = conv_bn_act(sd, prefix + ".local_rep.0", x, groups=c_in, training=training, bn_state=bn_state)
+    fm = conv_bn_act(sd, prefix + ".local_rep.1", fm, use_norm=False, use_act=False)
+    bb, c, hh, ww = fm.shape
+    patches = F.unfold(fm, kernel_size=(ph, pw), stride=(ph, pw)).reshape(bb, c, ph * pw, -1)
+    for i in range(n_blocks):
+        patches = linear_attn_ffn(sd, f"{prefix}.global_rep.{i}", patches)
+    patches = group_norm1(sd, f"{prefix}.global_rep.{n_blocks}", patches)
+    fm = F.fold(patches.reshape(bb, c * ph * pw, -1), output_size=(hh, ww), kernel_size=(ph, pw), stride=(ph, pw))
+    return conv_bn_act(sd, prefix + ".conv_proj", fm, use_act=False, training=training, bn_state=bn_state)
+
+
+def mobilevit_v2_forward(sd: Dict[str, Tensor], x: Tensor, width_multiplier: float = 1.0, training: bool = True,
+                         bn_state: Optional[BNState] = None) -> Tensor:
+    """MobileViTv2.forward (mobilevit_v2.py:29-96 + base_image_encoder.py:261-283); conv_1x1_exp is Identity,
+    classifier = GlobalPool(mean) -> LinearLayer."""
+    cfg = mobilevit_v2_config(width_multiplier)
+    x = conv_bn_act(sd, "conv_1", x, stride=2, training=training, bn_state=bn_state)
+    cin = cfg["layer0"]
+    for li in (1, 2):
+        c = cfg[f"layer{li}"]
+        for i in range(c["blocks"]):
+            x = inverted_residual(sd, f"layer_{li}.{i}", x, cin, c["out"], c["stride"] if i == 0 else 1, cfg["exp"], training, bn_state)
+            cin = c["out"]
+    for li in (3, 4, 5):
+        c = cfg[f"layer{li}"]
+        x = inverted_residual(sd, f"layer_{li}.0", x, cin, c["out"], 2, cfg["exp"], training, bn_state)
+        cin = c["out"]
+        x = mobilevit_block_v2(sd, f"layer_{li}.1", x, c["nblk"], training, bn_state)
+    x = torch.mean(x, dim=[-2, -1])
+    return F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])

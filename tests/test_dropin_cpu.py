@@ -112,3 +112,39 @@ def test_vit_class_swap(ref_model):
     assert ours.emb_dropout.p == model.emb_dropout.p
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 64, 64))
+
+
+def test_mobilevit_v2_class_swap(ref_model):
+    """the reference's MobileViTv2 builder (mobilevit_v2.yaml, width 2.0) -> class swap -> same tree as cvnets_amd.MobileViTv2."""
+    import yaml
+    import cvnets
+    import cvnets_amd
+    from cvnets_amd import dropin
+    from options.utils import flatten_yaml_as_dict
+
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+        opts = parser.parse_args([])
+        cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/classification/imagenet/mobilevit_v2.yaml")))
+        for k, v in cfg.items():
+            if hasattr(opts, k):
+                setattr(opts, k, v)
+        setattr(opts, "dataset.category", "classification")
+        setattr(opts, "dev.device", "cpu")
+        model = cvnets.get_model(opts)
+    finally:
+        os.chdir(cwd)
+    names_before = [n for n, _ in model.named_modules()]
+    keys_before = list(model.state_dict().keys())
+    counts, left = dropin.swap_to_hip(model, strict=True)
+    assert left == []
+    assert counts["MobileViTv2"] == 1 and counts["MobileViTBlockv2"] == 3 and counts["LinearAttnFFN"] == 9
+    assert counts["LinearSelfAttention"] == 9 and counts["LayerNorm2D_NCHW"] == 21
+    ours = cvnets_amd.MobileViTv2(opts)
+    assert [n for n, _ in ours.named_modules()] == names_before
+    assert list(ours.state_dict().keys()) == keys_before
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 64, 64))

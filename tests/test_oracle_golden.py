@@ -62,6 +62,28 @@ def test_vit_oracle_matches_reference_fixture(name, res):
             assert np.allclose(running[key[4:]].numpy(), gold[key], rtol=1e-5, atol=1e-6), key
 
 
+@pytest.mark.parametrize("name,wm,batch,hw", [("mobilevitv2_w050_64_b2", 0.5, 2, (64, 64)), ("mobilevitv2_w075_96x160_b3", 0.75, 3, (96, 160))])
+def test_v2_oracle_matches_reference_fixture(name, wm, batch, hw):
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    shapes = json.load(open(os.path.join(GOLD, f"mobilevitv2_w{int(round(wm * 100)):03d}_keys.json")))
+    sd = seeded_state_dict(shapes, seed=0)
+    x = seeded_input((batch, 3) + hw, seed=1)
+    y = seeded_labels(batch, 1000, seed=1)
+    assert np.allclose(orc.mobilevit_v2_forward(sd, x, width_multiplier=wm, training=False).numpy(), gold["logits_eval"], rtol=1e-4, atol=1e-5)
+    logits, loss, grads, running = orc.generic_train_step(orc.mobilevit_v2_forward, sd, x, y, width_multiplier=wm)
+    assert np.allclose(logits.numpy(), gold["logits_train"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5
+    names = [str(n) for n in gold["grad_names"]]
+    assert names == list(grads.keys())
+    assert np.allclose(np.array([grads[k].norm().item() for k in names]), gold["grad_norm"], rtol=1e-3, atol=1e-6)
+    for key in gold.files:
+        if key.startswith("grad::"):
+            assert np.allclose(grads[key[6:]].numpy(), gold[key], rtol=1e-3, atol=1e-6), key
+        if key.startswith("bn::"):
+            assert np.allclose(running[key[4:]].numpy(), gold[key], rtol=1e-5, atol=1e-6), key
+
+
 def test_oracle_mha_matches_reference_fixture():
     gold = np.load(os.path.join(GOLD, "mha_cases.npz"))
     for idx in range(4):

@@ -117,14 +117,14 @@ def test_vit_embed_fwd_bwd(dtype, has_cls):
     cls = torch.randn(E, generator=g) if has_cls else None
     S = N + int(has_cls)
     dout = torch.randn(B * S, E, generator=g).to(dtype)
-    pr, posr = patch.float().requires_grad_(), pos.clone().requires_grad_()
+    pr, posr = patch.float().clone().requires_grad_(), pos.clone().requires_grad_()
     clsr = cls.clone().requires_grad_() if has_cls else None
     t = pr.view(B, N, E) + posr
     if has_cls:
         t = torch.cat((clsr.view(1, 1, E).expand(B, -1, -1), t), dim=1)
     t.reshape(B * S, E).backward(dout.float())
-    pg, posg = patch.cuda().requires_grad_(), pos.cuda().requires_grad_()
-    clsg = cls.cuda().requires_grad_() if has_cls else None
+    pg, posg = patch.detach().cuda().requires_grad_(), pos.detach().cuda().requires_grad_()
+    clsg = cls.detach().cuda().requires_grad_() if has_cls else None
     out = ops.VitEmbed.apply(pg, posg, clsg, B)
     out.backward(dout.cuda())
     tol = 1e-6 if dtype == torch.float32 else 8e-3

@@ -124,6 +124,21 @@ int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void*
 int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream);
 int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream);
 
+/* ---- CLIP heads and loss ------------------------------------------------------------------------- */
+/* dst[r] = src[idx[r]] (scatter == 0) / dst[idx[r]] = src[r] (scatter == 1, dst pre-zeroed): the EOT-token gather
+ * token_emb[arange(B), text_tokens.argmax(-1)] (cvnets/text_encoders/transformer.py:413-421) and its adjoint. */
+int cvh_rows_gather_idx(int dtype, const void* src, const long long* idx, void* dst, int R, int C, int scatter, void* stream);
+/* F.normalize(x, dim=-1) (simple_projection_head.py:83-84, text_encoders/transformer.py:424-425); inv_norm[R] is saved for bwd */
+int cvh_l2norm_fwd(int dtype, const void* x, void* y, float* inv_norm, int R, int C, float eps, void* stream);
+int cvh_l2norm_bwd(int dtype, const void* y, const void* dy, const float* inv_norm, void* dx, int R, int C, float eps, void* stream);
+/* ContrastiveLossClip._forward_clip (loss_fn/multi_modal_img_text/contrastive_loss_clip.py:77-94): per-row cross-entropy of
+ * (*scale) * logits[N][M] against labels i + label_offset (= rank * N).  fwd: loss_rows[N], lse[N]; bwd: dlogits and per-row
+ * contributions to d(*scale), both already multiplied by the upstream scalar *gout. */
+int cvh_scaled_ce_fwd(int dtype, const void* logits, const float* scale, float* loss_rows, float* lse, int N, int M, int label_offset,
+                      void* stream);
+int cvh_scaled_ce_bwd(int dtype, const void* logits, const float* scale, const float* lse, const float* gout, void* dlogits,
+                      float* dscale_rows, int N, int M, int label_offset, void* stream);
+
 /* ---- MobileViTv2: GroupNorm(1) ("layer_norm_2d") and linear self-attention ------------------------------ */
 /* LayerNorm2D_NCHW = nn.GroupNorm(num_groups=1) (cvnets/layers/normalization/layer_norm.py:75-108) on an NHWC map [B][HW][C]:
  * per-sample statistics over HW*C, per-channel affine.  stats[B][2] = (mean, rstd) is written by fwd and read by bwd;

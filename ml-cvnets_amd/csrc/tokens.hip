@@ -118,6 +118,127 @@ __global__ void embed_lookup_bwd_kernel(const long long* __restrict__ tok, const
   }
 }
 
+// dst[b][:] = src[idx[b]][:]  (EOT-token rows, text_encoders/transformer.py:413-421) ; scatter form for the backward (dst pre-zeroed)
+template <typename T>
+__global__ void rows_gather_idx_kernel(const T* __restrict__ src, const long long* __restrict__ idx, T* __restrict__ dst, int R, int C, int scatter) {
+  const int cg = C / 8;
+  const size_t total = (size_t)R * cg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cg) * 8;
+    const size_t r = i / cg;
+    const size_t sr = (size_t)idx[r];
+    if (scatter) v8_store<T>(dst + sr * C + c0, v8_load<T>(src + r * C + c0));
+    else v8_store<T>(dst + r * C + c0, v8_load<T>(src + sr * C + c0));
+  }
+}
+
+// F.normalize(x, dim=-1): y = x / max(||x||_2, eps) — one wave per row (simple_projection_head.py:83-84, transformer.py:424-425)
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ inv_norm, int R, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const T* xr = x + (size_t)r * C;
+  float ss = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    float f[8];
+    v8_unpack(v8_load<T>(xr + c), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), eps);
+  if (lane == 0) inv_norm[r] = inv;
+  for (int c = lane * 8; c < C; c += 512) {
+    float f[8];
+    v8_unpack(v8_load<T>(xr + c), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= inv;
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(y + (size_t)r * C + c, o);
+  }
+}
+// dx = inv * (dy - y * <dy, y>)   (rows whose norm was clamped by eps: dx = inv * dy)
+template <typename T>
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, const float* __restrict__ inv_norm,
+                                                         T* __restrict__ dx, int R, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float inv = inv_norm[r];
+  const bool clamped = inv >= 1.0f / eps;
+  float dot = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    float a[8], b[8];
+    v8_unpack(v8_load<T>(y + (size_t)r * C + c), a);
+    v8_unpack(v8_load<T>(dy + (size_t)r * C + c), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += a[j] * b[j];
+  }
+  dot = clamped ? 0.f : wave_sum(dot);
+  for (int c = lane * 8; c < C; c += 512) {
+    float a[8], b[8];
+    v8_unpack(v8_load<T>(y + (size_t)r * C + c), a);
+    v8_unpack(v8_load<T>(dy + (size_t)r * C + c), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = inv * (b[j] - a[j] * dot);
+    V8<T> o;
+    v8_pack(a, o);
+    v8_store<T>(dx + (size_t)r * C + c, o);
+  }
+}
+
+// Contrastive cross-entropy (contrastive_loss_clip.py:77-94): z = scale * logits[i][:], label_i = i + label_offset;
+// loss_rows[i] = logsumexp(z) - z[label] ; lse[i] saved.  One 256-thread block per row.
+template <typename T>
+__global__ void __launch_bounds__(256) scaled_ce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ scale, float* __restrict__ loss_rows,
+                                                            float* __restrict__ lse, int N, int M, int label_offset) {
+  __shared__ float scr[8];
+  const int i = blockIdx.x;
+  const float s = *scale;
+  const T* row = logits + (size_t)i * M;
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < M; j += 256) mx = fmaxf(mx, s * to_f<T>(row[j]));
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) sum += __expf(s * to_f<T>(row[j]) - mx);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) scr[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l = mx + __logf(scr[4] + scr[5] + scr[6] + scr[7]);
+    lse[i] = l;
+    loss_rows[i] = l - s * to_f<T>(row[i + label_offset]);
+  }
+}
+// dlogits[i][j] = g * scale * (softmax_ij - [j == label_i]) ; dscale_rows[i] = g * sum_j logits_ij * (softmax_ij - [j == label_i])
+// (g = upstream gradient per row, e.g. 0.5 / N)
+template <typename T>
+__global__ void __launch_bounds__(256) scaled_ce_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ scale, const float* __restrict__ lse,
+                                                            const float* __restrict__ gout, T* __restrict__ dlogits, float* __restrict__ dscale_rows,
+                                                            int N, int M, int label_offset) {
+  __shared__ float scr[4];
+  const int i = blockIdx.x;
+  const float s = *scale, l = lse[i], g = *gout;
+  const T* row = logits + (size_t)i * M;
+  const int label = i + label_offset;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const float x = to_f<T>(row[j]);
+    const float d = __expf(s * x - l) - (j == label ? 1.f : 0.f);
+    acc += x * d;
+    dlogits[(size_t)i * M + j] = from_f<T>(g * s * d);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dscale_rows[i] = g * (scr[0] + scr[1] + scr[2] + scr[3]);
+}
+
 static inline int tk_grid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
@@ -170,6 +291,39 @@ extern "C" int cvh_embed_lookup_bwd(int dtype, const long long* tok, const void*
   if (E % 8) return -2;
   const size_t total = (size_t)rows * (E / 8);
   TK_DISPATCH(dtype, hipLaunchKernelGGL((embed_lookup_bwd_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, tok, (const T*)dout, dtable, (size_t)rows, E, padding_idx);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_rows_gather_idx(int dtype, const void* src, const long long* idx, void* dst, int R, int C, int scatter, void* stream) {
+  if (C % 8) return -2;
+  const size_t total = (size_t)R * (C / 8);
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((rows_gather_idx_kernel<T>), dim3(tk_grid(total)), dim3(256), 0, (hipStream_t)stream, (const T*)src, idx, (T*)dst, R, C, scatter);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_l2norm_fwd(int dtype, const void* x, void* y, float* inv_norm, int R, int C, float eps, void* stream) {
+  if (C % 8) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((l2norm_fwd_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, inv_norm, R, C, eps);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_l2norm_bwd(int dtype, const void* y, const void* dy, const float* inv_norm, void* dx, int R, int C, float eps, void* stream) {
+  if (C % 8) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((l2norm_bwd_kernel<T>), dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)dy, inv_norm, (T*)dx, R, C, eps);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_scaled_ce_fwd(int dtype, const void* logits, const float* scale, float* loss_rows, float* lse, int N, int M, int label_offset,
+                                 void* stream) {
+  if (N <= 0 || M <= 0 || label_offset < 0 || N + label_offset > M) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((scaled_ce_fwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, scale, loss_rows, lse, N, M, label_offset);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_scaled_ce_bwd(int dtype, const void* logits, const float* scale, const float* lse, const float* gout, void* dlogits,
+                                 float* dscale_rows, int N, int M, int label_offset, void* stream) {
+  if (N <= 0 || M <= 0 || label_offset < 0 || N + label_offset > M) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((scaled_ce_bwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, scale, lse, gout, (T*)dlogits, dscale_rows, N, M, label_offset);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

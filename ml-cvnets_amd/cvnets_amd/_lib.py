@@ -51,6 +51,11 @@ SIGNATURES = {
     "cvh_dropout": [I, P, P, L, F, P, U, P],
     "cvh_seed_advance": [P, P],
     "cvh_add": [I, P, P, P, L, P],
+    "cvh_rows_gather_idx": [I, P, P, P, I, I, I, P],
+    "cvh_l2norm_fwd": [I, P, P, P, I, I, F, P],
+    "cvh_l2norm_bwd": [I, P, P, P, P, I, I, F, P],
+    "cvh_scaled_ce_fwd": [I, P, P, P, P, I, I, I, P],
+    "cvh_scaled_ce_bwd": [I, P, P, P, P, P, P, I, I, I, P],
     "cvh_gn_chunks": [I, I, I],
     "cvh_gn_fwd": [I, P, P, P, P, P, P, I, I, I, F, P],
     "cvh_gn_bwd": [I, P, P, P, P, P, P, P, I, I, I, P],

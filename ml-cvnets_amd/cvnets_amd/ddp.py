@@ -160,3 +160,37 @@ class DistributedDataParallel(nn.Module):
                     b.copy_(flat[off: off + b.numel()].view_as(b))
                     off += b.numel()
         return self.module(*args, **kwargs)
+
+
+class _AllGatherWithGrad(torch.autograd.Function):
+    """utils/tensor_utils.py:121-122 (gather_all_features -> torch.distributed.nn.all_gather): forward = all-gather along dim 0
+    (one RCCL collective into a contiguous [W*N, d] buffer), backward = reduce-scatter(sum) of the gathered gradient — every rank
+    receives the sum over ranks of the gradient slices that belong to its own rows."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        x = x.contiguous()
+        world = dist.get_world_size(group)
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        ctx.group = group
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        world, rank = dist.get_world_size(ctx.group), dist.get_rank(ctx.group)
+        if dist.get_backend(ctx.group) == "gloo":  # gloo has no reduce-scatter: all-reduce, keep the own slice (CPU tests only)
+            dist.all_reduce(g, group=ctx.group)
+            return g[rank * ctx.n:(rank + 1) * ctx.n].clone(), None
+        out = torch.empty((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        dist.reduce_scatter_tensor(out, g, group=ctx.group)
+        return out, None
+
+
+def gather_all_features(features: torch.Tensor, group=None) -> torch.Tensor:
+    """[N, d] on every rank -> [W*N, d], differentiable (ContrastiveLossClip, contrastive_loss_clip.py:144-172)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return features
+    return _AllGatherWithGrad.apply(features, group)

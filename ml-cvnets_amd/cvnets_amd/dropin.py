@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 from torch import nn
 
-from . import layers, models, modules
+from . import clip, layers, models, modules
 
 # reference class name -> cvnets_amd class (matched by name AND by defining package to avoid swapping foreign classes)
 _BY_NAME = {
@@ -41,6 +41,11 @@ _BY_NAME = {
     "LinearAttnFFN": modules.LinearAttnFFN,
     "MobileViTBlockv2": modules.MobileViTBlockv2,
     "MobileViTv2": models.MobileViTv2,
+    "LayerNormFP32": layers.LayerNormFP32,
+    "Embedding": layers.Embedding,
+    "TextTransformer": clip.TextTransformer,
+    "SimpleImageProjectionHead": clip.SimpleImageProjectionHead,
+    "CLIP": clip.CLIP,
 }
 
 

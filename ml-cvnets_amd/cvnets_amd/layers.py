@@ -141,6 +141,11 @@ class LayerNorm(nn.LayerNorm):
         return y.view(shp)
 
 
+class LayerNormFP32(LayerNorm):
+    """cvnets/layers/normalization/layer_norm.py:111-137: LayerNorm evaluated in fp32 whatever the activation dtype.  The HIP
+    LayerNorm kernel always accumulates statistics and applies the affine in fp32 and rounds once on store, so the two coincide."""
+
+
 class LayerNorm2D_NCHW(nn.GroupNorm):
     """cvnets/layers/normalization/layer_norm.py:75-108: nn.GroupNorm(num_groups=1) — statistics over (C, H, W) of each sample."""
 
@@ -157,7 +162,7 @@ class LayerNorm2D_NCHW(nn.GroupNorm):
         return "{}(num_channels={}, eps={}, affine={})".format(self.__class__.__name__, self.num_channels, self.eps, self.affine)
 
 
-NORM_LAYER_REGISTRY = {"batch_norm": BatchNorm2d, "batch_norm_2d": BatchNorm2d, "layer_norm": LayerNorm,
+NORM_LAYER_REGISTRY = {"batch_norm": BatchNorm2d, "batch_norm_2d": BatchNorm2d, "layer_norm": LayerNorm, "layer_norm_fp32": LayerNormFP32,
                        "layer_norm_2d": LayerNorm2D_NCHW, "layer_norm_nchw": LayerNorm2D_NCHW}
 
 
@@ -370,8 +375,11 @@ class LearnablePositionalEmbedding(nn.Module):
     def forward(self, seq_len: int, *args, **kwargs) -> Tensor:
         """returns the [seq_len, E] float32 table (bilinearly resized along the sequence axis when seq_len differs,
         positional_embedding.py:90-95); the batch broadcast happens inside the embedding kernel."""
-        if self.padding_idx is not None or self.interpolation_mode != "bilinear":
-            raise NotImplementedError("padding_idx / non-bilinear positional embeddings are not on the HIP hot path")
+        if self.interpolation_mode != "bilinear":
+            raise NotImplementedError("non-bilinear positional embeddings are not on the HIP hot path")
+        if self.padding_idx is not None:  # positional_embedding.py:84-86: the padding position is re-zeroed on every call
+            with torch.no_grad():
+                self.pos_embed[:, :, self.padding_idx, ...] = 0.0
         pe = self.pos_embed.view(self.num_embeddings, self.embedding_dim)
         if seq_len != self.num_embeddings:
             # [N, E] is an NHWC map with H = N, W = 1, C = E: resizing H only is F.interpolate(size=(seq_len, E)) on [1,1,N,E]
@@ -398,6 +406,26 @@ class PositionalEmbedding(nn.Module):
 
     def __repr__(self):
         return self.pos_embed.__repr__()
+
+
+# ---------------------------------------------------------------------------------------------
+# token embedding  (cvnets/layers/embedding.py:15-60)
+# ---------------------------------------------------------------------------------------------
+class Embedding(nn.Embedding):
+    def __init__(self, opts, num_embeddings: int, embedding_dim: int, padding_idx: Optional[int] = None, *args, **kwargs):
+        super().__init__(num_embeddings=num_embeddings, embedding_dim=embedding_dim, padding_idx=padding_idx)
+
+    def reset_parameters(self) -> None:
+        nn.init.normal_(self.weight, mean=0, std=self.embedding_dim ** -0.5)
+        if self.padding_idx is not None:
+            nn.init.constant_(self.weight[self.padding_idx], 0)
+
+    def forward(self, tokens: Tensor, pos: Optional[Tensor] = None) -> Tensor:
+        """tokens [B, S] -> [B, S, E] (+ pos [S, E] added in the same kernel)"""
+        if tokens.dim() != 2:
+            raise NotImplementedError("Embedding expects [batch, sequence] token ids on the HIP hot path")
+        y = ops.EmbedLookup.apply(tokens, self.weight, pos, self.padding_idx, ops.compute_dtype())
+        return y.view(tokens.shape[0], tokens.shape[1], self.embedding_dim)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -897,6 +897,118 @@ class RowsGather(torch.autograd.Function):
         return dx, None, None, None
 
 
+class EmbedLookup(torch.autograd.Function):
+    """token embedding + positional embedding for the text tower (cvnets/text_encoders/transformer.py:321-341):
+    tokens [B, S] int64, table [V, E] fp32, pos [S, E] fp32 or None -> [B*S, E] in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, pos, padding_idx, dtype):
+        _check_dev(table)
+        B, S = tokens.shape
+        V, E = table.shape
+        tokens = tokens.contiguous()
+        out = torch.empty((B * S, E), dtype=dtype, device=table.device)
+        _lib.call("cvh_embed_lookup_fwd", _dt(out), _p(tokens), _p(table), _p(pos), _p(out), B * S, S, E, _stream())
+        ctx.save_for_backward(tokens)
+        ctx.meta = (B, S, V, E, -1 if padding_idx is None else int(padding_idx), pos is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        B, S, V, E, pad, has_pos = ctx.meta
+        dout = dout.contiguous()
+        dtable = torch.zeros((V, E), dtype=torch.float32, device=dout.device)  # plumbing: scatter-add target
+        _lib.call("cvh_embed_lookup_bwd", _dt(dout), _p(tokens), _p(dout), _p(dtable), B * S, E, pad, _stream())
+        dpos = None
+        if has_pos:
+            dpos = _f32(S * E, dout.device).view(S, E)
+            _lib.call("cvh_batch_sum", _dt(dout), _p(dout), _p(dpos), B, S * E, 0, _stream())
+        return None, dtable, dpos, None, None
+
+
+class RowsGatherIdx(torch.autograd.Function):
+    """x [R_src, C], rows int64 [R] -> x[rows]  (EOT-token embeddings, text_encoders/transformer.py:413-421)."""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        _check_dev(x)
+        R, C = rows.shape[0], x.shape[1]
+        y = torch.empty((R, C), dtype=x.dtype, device=x.device)
+        _lib.call("cvh_rows_gather_idx", _dt(x), _p(x), _p(rows), _p(y), R, C, 0, _stream())
+        ctx.save_for_backward(rows)
+        ctx.n_src = x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.zeros((ctx.n_src, dy.shape[1]), dtype=dy.dtype, device=dy.device)  # plumbing: all other rows have zero gradient
+        _lib.call("cvh_rows_gather_idx", _dt(dy), _p(dy), _p(rows), _p(dx), rows.shape[0], dy.shape[1], 1, _stream())
+        return dx, None
+
+
+class L2Normalize(torch.autograd.Function):
+    """F.normalize(x, dim=-1) on [R, C]."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _check_dev(x)
+        x = x.contiguous()
+        R, C = x.shape
+        y = torch.empty_like(x)
+        inv = _f32(R, x.device)
+        _lib.call("cvh_l2norm_fwd", _dt(x), _p(x), _p(y), _p(inv), R, C, float(eps), _stream())
+        ctx.save_for_backward(y, inv)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.call("cvh_l2norm_bwd", _dt(y), _p(y), _p(dy), _p(inv), _p(dx), y.shape[0], y.shape[1], ctx.eps, _stream())
+        return dx, None
+
+
+def l2_normalize(x, eps: float = 1e-12):
+    return L2Normalize.apply(x, eps)
+
+
+class ScaledCrossEntropy(torch.autograd.Function):
+    """mean_i CE(scale * logits[i], i + label_offset)  (contrastive_loss_clip.py:77-94).  logits [N, M]; scale: 0-d fp32 tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, scale, label_offset):
+        _check_dev(logits)
+        logits = logits.contiguous()
+        N, M = logits.shape
+        scale = scale.detach().float().reshape(1)  # plumbing: scalar
+        rows = _f32(N, logits.device)
+        lse = _f32(N, logits.device)
+        _lib.call("cvh_scaled_ce_fwd", _dt(logits), _p(logits), _p(scale), _p(rows), _p(lse), N, M, int(label_offset), _stream())
+        ctx.save_for_backward(logits, scale, lse)
+        ctx.label_offset = int(label_offset)
+        return rows.mean()  # plumbing: N-element reduction
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, scale, lse = ctx.saved_tensors
+        N, M = logits.shape
+        gout = (g.float() / N).reshape(1)  # plumbing: scalar
+        dlogits = torch.empty_like(logits)
+        ds_rows = _f32(N, logits.device)
+        _lib.call("cvh_scaled_ce_bwd", _dt(logits), _p(logits), _p(scale), _p(lse), _p(gout), _p(dlogits), _p(ds_rows), N, M, ctx.label_offset,
+                  _stream())
+        return dlogits, ds_rows.sum().reshape(()), None
+
+
+def scaled_cross_entropy(logits, scale, label_offset: int = 0):
+    return ScaledCrossEntropy.apply(logits, scale, int(label_offset))
+
+
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, stream_id):

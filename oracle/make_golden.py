@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import yaml  # noqa: E402
 
 from oracle import mobilevit_oracle as orc  # noqa: E402
+from oracle.weights import seeded_caption_tokens as clip_tokens  # noqa: E402
 from oracle.weights import seeded_input, seeded_labels, seeded_state_dict  # noqa: E402
 
 CASES = [
@@ -334,6 +335,96 @@ def run_v2_case(name, wm, batch, res, outdir):
         json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
 
 
+CLIP_CASE = dict(name="clip_tiny_64_b8", vit_mode="tiny", res=64, batch=8, text_dim=64, text_layers=2, text_heads=2, vocab=200, ctx=16, proj=64)
+CLIP_FULL_GRADS = ["logit_scale", "image_encoder.classifier.proj", "image_encoder.cls_token", "image_encoder.patch_emb.1.block.conv.weight",
+                   "text_encoder.projection_layer", "text_encoder.embedding_layer.weight", "text_encoder.positional_embedding.pos_embed.pos_embed",
+                   "text_encoder.transformer.0.pre_norm_mha.1.qkv_proj.weight", "text_encoder.transformer.1.pre_norm_ffn.4.bias",
+                   "text_encoder.final_layer_norm.weight"]
+
+
+def build_reference_clip(c):
+    os.chdir(REF)
+    import cvnets
+    from options.utils import flatten_yaml_as_dict
+
+    parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+    opts = parser.parse_args([])
+    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/multi_modal_img_text/clip_vit.yaml")))
+    for k, v in cfg.items():
+        if hasattr(opts, k):
+            setattr(opts, k, v)
+    for k, v in {"dataset.category": "multi_modal_image_text", "dev.device": "cpu", "dataset.text_vocab_size": c["vocab"],
+                 "dataset.text_context_length": c["ctx"], "dataset.padding_index": 0, "ddp.use_distributed": False, "ddp.rank": 0,
+                 "model.classification.vit.mode": c["vit_mode"], "model.classification.vit.dropout": 0.0,
+                 "model.classification.gradient_checkpointing": False, "model.text.transformer.gradient_checkpoint": False,
+                 "model.text.transformer.model_dim": c["text_dim"], "model.text.transformer.n_transformer_layers": c["text_layers"],
+                 "model.text.transformer.n_heads_per_layer": c["text_heads"],
+                 "model.multi_modal_image_text.clip.projection_dim": c["proj"]}.items():
+        setattr(opts, k, v)
+    model = cvnets.get_model(opts)
+    model.image_encoder.emb_dropout.p = 0.0
+    sys.path.insert(0, REF)
+    from loss_fn.multi_modal_img_text.contrastive_loss_clip import ContrastiveLossClip
+    return model, ContrastiveLossClip(opts), opts
+
+
+def run_clip_case(outdir):
+    c = CLIP_CASE
+    torch.manual_seed(0)
+    model, loss_fn, _ = build_reference_clip(c)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    sd["logit_scale"] = torch.tensor(float(np.log(1.0 / 0.07)))
+    sd["image_encoder.cls_token"] = 0.02 * seeded_state_dict({"cls_token_values": shapes["image_encoder.cls_token"]}, seed=0)["cls_token_values"]
+    model.load_state_dict(sd, strict=True)
+    x = seeded_input((c["batch"], 3, c["res"], c["res"]), seed=1)
+    tok = clip_tokens(c["batch"], c["ctx"], c["vocab"], seed=1)
+    model.train()
+    loss_fn.train()
+
+    def run():
+        model.zero_grad()
+        out = model({"image": x, "text": tok})
+        img, txt = out["image"].detach().clone(), out["text"].detach().clone()
+        loss = loss_fn(None, out)["total_loss"]
+        loss.backward()
+        return img, txt, loss.detach().clone(), {k: p.grad.detach().clone().float() for k, p in model.named_parameters()}
+
+    img, txt, loss, ref_grads = run()
+    ref_sd_after = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        img_b, txt_b, loss_b, gb = run()
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+    gmax = max(v.norm().item() for v in ref_grads.values())
+    bf16_ref = {"image": rel(img_b.float(), img), "text": rel(txt_b.float(), txt), "loss": abs(float(loss_b) - float(loss)),
+                "grad_global": (sum(float((gb[k].double() - ref_grads[k].double()).pow(2).sum()) for k in gb) /
+                                sum(float(ref_grads[k].double().pow(2).sum()) for k in gb)) ** 0.5,
+                "grad_norm_worst": max(abs(gb[k].norm().item() - ref_grads[k].norm().item()) / (ref_grads[k].norm().item() + 1e-3 * gmax) for k in gb),
+                "grad_full_worst": max(rel(gb[k], ref_grads[k]) for k in CLIP_FULL_GRADS)}
+    print(c["name"], "reference bf16-autocast vs fp32:", {k: f"{v:.2e}" for k, v in bf16_ref.items()})
+    kw = dict(vit_mode=c["vit_mode"], text_layers=c["text_layers"], text_heads=c["text_heads"])
+    o_img, o_txt, o_loss, o_grads, o_running = orc.clip_train_step(sd, x, tok, **kw)
+    checks = {"image": rel(o_img, img), "text": rel(o_txt, txt), "loss": abs(float(o_loss) - float(loss)),
+              "grad_worst_rel": max(rel(o_grads[k], ref_grads[k]) for k in ref_grads if ref_grads[k].norm() > 1e-6 * gmax),
+              "bn_running_worst_rel": max(rel(v, ref_sd_after[k]) for k, v in o_running.items())}
+    print(c["name"], {k: f"{v:.2e}" for k, v in checks.items()})
+    assert max(checks["image"], checks["text"], checks["loss"]) < 1e-5 and checks["grad_worst_rel"] < 2e-4, checks
+    names = list(ref_grads.keys())
+    out = {"image": img.numpy(), "text": txt.numpy(), "loss": np.float32(loss.item()), "tokens": tok.numpy(),
+           "grad_names": np.array(names), "grad_norm": np.array([ref_grads[k].norm().item() for k in names], dtype=np.float64),
+           "oracle_vs_reference": np.array(json.dumps(checks)), "ref_bf16_autocast_err": np.array(json.dumps(bf16_ref)),
+           "config": np.array(json.dumps(c))}
+    for k in CLIP_FULL_GRADS:
+        out["grad::" + k] = ref_grads[k].numpy()
+    np.savez_compressed(os.path.join(outdir, c["name"] + ".npz"), **out)
+    with open(os.path.join(outdir, "clip_tiny_keys.json"), "w") as f:
+        json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
+
+
 def mha_cases(outdir):
     """Pins oracle.multi_head_attention / transformer_encoder against the reference layer incl.
     masks (the only numerical cross-check the reference's own tests hold for this path:
@@ -382,4 +473,5 @@ if __name__ == "__main__":
         run_vit_case(*c, outdir)
     for c in V2_CASES:
         run_v2_case(*c, outdir)
+    run_clip_case(outdir)
     print("golden fixtures written to", outdir)

@@ -300,21 +300,24 @@ def positional_embedding(sd, prefix: str, seq_len: int) -> Tensor:
 
 
 def vit_forward(sd: Dict[str, Tensor], x: Tensor, mode: str = "tiny", training: bool = True,
-                bn_state: Optional[BNState] = None) -> Tensor:
+                bn_state: Optional[BNState] = None, prefix: str = "", head: str = "classifier") -> Tensor:
     """VisionTransformer.forward -> forward_classifier -> extract_features -> _features_from_transformer ->
     extract_patch_embeddings (vit.py:480-610), dropout p = 0, default (batch-first) MHA."""
     e, n_layers, heads = VIT_CFG[mode]
-    y = conv_bn_act(sd, "patch_emb.0", x, stride=4, training=training, bn_state=bn_state, act="gelu")
-    y = conv_bn_act(sd, "patch_emb.1", y, stride=2, training=training, bn_state=bn_state, act="gelu")
-    y = conv_bn_act(sd, "patch_emb.2", y, stride=2, use_norm=False, use_act=False)
+    p = prefix
+    y = conv_bn_act(sd, p + "patch_emb.0", x, stride=4, training=training, bn_state=bn_state, act="gelu")
+    y = conv_bn_act(sd, p + "patch_emb.1", y, stride=2, training=training, bn_state=bn_state, act="gelu")
+    y = conv_bn_act(sd, p + "patch_emb.2", y, stride=2, use_norm=False, use_act=False)
     b = y.shape[0]
     t = y.flatten(2).transpose(1, 2).contiguous()
-    t = positional_embedding(sd, "pos_embed", t.shape[1]).to(t.dtype) + t
-    t = torch.cat((sd["cls_token"].expand(b, -1, -1), t), dim=1)
+    t = positional_embedding(sd, p + "pos_embed", t.shape[1]).to(t.dtype) + t
+    t = torch.cat((sd[p + "cls_token"].expand(b, -1, -1), t), dim=1)
     for i in range(n_layers):
-        t = transformer_encoder(sd, f"transformer.{i}", t, heads, act="gelu", ln_eps=1e-6)
-    t = F.layer_norm(t, (e,), sd["post_transformer_norm.weight"], sd["post_transformer_norm.bias"], 1e-6)
-    return F.linear(t[:, 0], sd["classifier.weight"], sd["classifier.bias"])
+        t = transformer_encoder(sd, f"{p}transformer.{i}", t, heads, act="gelu", ln_eps=1e-6)
+    t = F.layer_norm(t, (e,), sd[p + "post_transformer_norm.weight"], sd[p + "post_transformer_norm.bias"], 1e-6)
+    if head == "projection":  # SimpleImageProjectionHead.forward (cvnets/image_projection_layers/simple_projection_head.py:74-85)
+        return F.normalize(t[:, 0] @ sd[p + "classifier.proj"], dim=-1)
+    return F.linear(t[:, 0], sd[p + "classifier.weight"], sd[p + "classifier.bias"])
 
 
 def generic_train_step(forward_fn, sd: Dict[str, Tensor], x: Tensor, y: Tensor, label_smoothing: float = 0.1, **kw):
@@ -403,3 +406,64 @@ def mobilevit_v2_forward(sd: Dict[str, Tensor], x: Tensor, width_multiplier: flo
         x = mobilevit_block_v2(sd, f"layer_{li}.1", x, c["nblk"], training, bn_state)
     x = torch.mean(x, dim=[-2, -1])
     return F.linear(x, sd["classifier.1.weight"], sd["classifier.1.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# CLIP  (cvnets/models/multi_modal_img_text/clip.py:144-210; cvnets/text_encoders/transformer.py:321-426;
+#        loss_fn/multi_modal_img_text/contrastive_loss_clip.py:35-103)
+# --------------------------------------------------------------------------------------
+def text_transformer_forward(sd: Dict[str, Tensor], prefix: str, tokens: Tensor, n_layers: int, heads: int, causal: bool = True,
+                             padding_idx: Optional[int] = 0) -> Tensor:
+    """TextTransformer.forward -> encode_text (transformer.py:354-426): token + positional embedding (position `padding_idx` of the
+    table is re-zeroed in place on every call, positional_embedding.py:84-86), causal pre-norm GELU transformer, final LayerNorm,
+    EOT (= arg-max token id) row, projection, L2 normalisation."""
+    emb = F.embedding(tokens, sd[prefix + "embedding_layer.weight"], padding_idx)
+    pe = sd[prefix + "positional_embedding.pos_embed.pos_embed"]
+    if padding_idx is not None:
+        with torch.no_grad():
+            pe[:, :, padding_idx, ...] = 0.0
+    s = tokens.shape[1]
+    if s != pe.shape[2]:
+        pe = F.interpolate(pe, size=(s, pe.shape[3]), mode="bilinear")
+    x = emb + pe.reshape(1, s, -1).to(emb.dtype)
+    mask = None
+    if causal:
+        mask = torch.full((s, s), float("-inf")).triu_(1).unsqueeze(0).expand(tokens.shape[0], -1, -1)
+    for i in range(n_layers):
+        x = transformer_encoder(sd, f"{prefix}transformer.{i}", x, heads, act="gelu", attn_mask=mask)
+    x = F.layer_norm(x, (x.shape[-1],), sd[prefix + "final_layer_norm.weight"], sd[prefix + "final_layer_norm.bias"], 1e-5)
+    x = x[torch.arange(tokens.shape[0]), tokens.argmax(dim=-1)]
+    return F.normalize(x @ sd[prefix + "projection_layer"], dim=-1)
+
+
+def clip_forward(sd: Dict[str, Tensor], image: Tensor, tokens: Tensor, vit_mode: str, text_layers: int, text_heads: int,
+                 training: bool = True, bn_state: Optional[BNState] = None):
+    """CLIP.forward (clip.py:144-210), training branch: (image embeddings, text embeddings, clamped exp(logit_scale))."""
+    img = vit_forward(sd, image, mode=vit_mode, training=training, bn_state=bn_state, prefix="image_encoder.", head="projection")
+    txt = text_transformer_forward(sd, "text_encoder.", tokens, text_layers, text_heads)
+    return img, txt, torch.clamp(sd["logit_scale"].exp(), 0, 100.0)
+
+
+def contrastive_loss_clip(img: Tensor, txt: Tensor, logit_scale: Tensor, all_img: Optional[Tensor] = None, all_txt: Optional[Tensor] = None,
+                          rank: int = 0):
+    """ContrastiveLossClip._forward_clip (contrastive_loss_clip.py:35-103); all_* = features gathered over ranks (None: 1 rank)."""
+    all_img = img if all_img is None else all_img
+    all_txt = txt if all_txt is None else all_txt
+    logits_per_image = logit_scale * (img @ all_txt.transpose(0, 1))
+    logits_per_text = logit_scale * (txt @ all_img.transpose(0, 1))
+    n = logits_per_image.shape[0]
+    labels = torch.arange(n, dtype=torch.long) + n * rank
+    text_loss = F.cross_entropy(logits_per_text, labels) * 0.5
+    image_loss = F.cross_entropy(logits_per_image, labels) * 0.5
+    return image_loss + text_loss, image_loss, text_loss
+
+
+def clip_train_step(sd: Dict[str, Tensor], image: Tensor, tokens: Tensor, **kw):
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    st = BNState()
+    img, txt, scale = clip_forward(params, image, tokens, training=True, bn_state=st, **kw)
+    loss, _, _ = contrastive_loss_clip(img, txt, scale)
+    names = [k for k, v in params.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(params[k]) for g, k in zip(grads, names)]
+    return img.detach(), txt.detach(), loss.detach(), dict(zip(names, grads)), st.running

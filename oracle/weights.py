@@ -45,3 +45,15 @@ def seeded_input(shape: Tuple[int, ...], seed: int = 0, name: str = "input") -> 
 def seeded_labels(n: int, n_classes: int = 1000, seed: int = 0) -> torch.Tensor:
     rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(b"labels")]))
     return torch.from_numpy(rng.integers(0, n_classes, size=(n,)).astype(np.int64))
+
+
+def seeded_caption_tokens(batch: int, ctx: int, vocab: int, seed: int) -> torch.Tensor:
+    """synthetic captions for the CLIP text tower: ids in [1, vocab-2], one EOT (= vocab-1, the arg-max id read by
+    text_encoders/transformer.py:413-421) at a random position >= 4, padding (0) after it."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tok = rng.integers(1, vocab - 1, size=(batch, ctx))
+    for b in range(batch):
+        e = int(rng.integers(4, ctx))
+        tok[b, e] = vocab - 1
+        tok[b, e + 1:] = 0
+    return torch.from_numpy(tok.astype(np.int64))

@@ -83,3 +83,49 @@ def test_ddp_gloo_world2(explicit):
     res = sorted(q.get(timeout=5) for _ in range(2))
     for rank, err, ok in res:
         assert err < 1e-6 and ok, (rank, err)
+
+
+def _gather_worker(rank, world, port, q):
+    """contrastive loss over 2 ranks (gloo): the differentiable all-gather must reproduce the single-process loss / gradients of
+    the oracle's ContrastiveLossClip restatement evaluated on the concatenated batch (contrastive_loss_clip.py:35-103, 144-172)."""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.nn.functional as F
+    from cvnets_amd.ddp import distributed_init, gather_all_features
+    from oracle import mobilevit_oracle as orc
+
+    distributed_init("gloo", torch.device("cpu"))
+    n, d = 4, 16
+    g = torch.Generator().manual_seed(3)
+    img_all = F.normalize(torch.randn(world * n, d, generator=g), dim=-1)
+    txt_all = F.normalize(torch.randn(world * n, d, generator=g), dim=-1)
+    scale = torch.tensor(10.0)
+    img = img_all[rank * n:(rank + 1) * n].clone().requires_grad_()
+    txt = txt_all[rank * n:(rank + 1) * n].clone().requires_grad_()
+    gi, gt = gather_all_features(img), gather_all_features(txt)
+    assert torch.equal(gi.detach(), img_all) and torch.equal(gt.detach(), txt_all)
+    loss, _, _ = orc.contrastive_loss_clip(img, txt, scale, gi, gt, rank=rank)
+    loss.backward()
+    # single-process reference: the mean over ranks of the per-rank losses == loss of the full batch; d(sum of rank losses)/d(local)
+    ia, ta = img_all.clone().requires_grad_(), txt_all.clone().requires_grad_()
+    total = sum(orc.contrastive_loss_clip(ia[r * n:(r + 1) * n], ta[r * n:(r + 1) * n], scale, ia, ta, rank=r)[0] for r in range(world))
+    total.backward()
+    full, _, _ = orc.contrastive_loss_clip(img_all, txt_all, scale)
+    err = max(float((img.grad - ia.grad[rank * n:(rank + 1) * n]).abs().max()), float((txt.grad - ta.grad[rank * n:(rank + 1) * n]).abs().max()))
+    q.put((rank, err, abs(float(total) / world - float(full))))
+    dist.destroy_process_group()
+
+
+def test_gather_all_features_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, err, dl in sorted(q.get(timeout=5) for _ in range(2)):
+        assert err < 1e-6 and dl < 1e-6, (rank, err, dl)

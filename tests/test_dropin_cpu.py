@@ -148,3 +148,40 @@ def test_mobilevit_v2_class_swap(ref_model):
     assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in model.state_dict().items()}
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 64, 64))
+
+
+def test_clip_class_swap(ref_model):
+    """the reference's CLIP builder (clip_vit.yaml, ViT-B/16 + 12-layer text transformer) -> class swap -> same tree as cvnets_amd.CLIP."""
+    import yaml
+    import cvnets
+    import cvnets_amd
+    from cvnets_amd import dropin
+    from options.utils import flatten_yaml_as_dict
+
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+        opts = parser.parse_args([])
+        cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/multi_modal_img_text/clip_vit.yaml")))
+        for k, v in cfg.items():
+            if hasattr(opts, k):
+                setattr(opts, k, v)
+        for k, v in {"dataset.category": "multi_modal_image_text", "dev.device": "cpu", "dataset.text_vocab_size": 49408,
+                     "dataset.text_context_length": 77, "dataset.padding_index": 0, "ddp.use_distributed": False, "ddp.rank": 0,
+                     "model.classification.vit.mode": "tiny", "model.text.transformer.n_transformer_layers": 2}.items():
+            setattr(opts, k, v)
+        model = cvnets.get_model(opts)
+    finally:
+        os.chdir(cwd)
+    names_before = [n for n, _ in model.named_modules()]
+    keys_before = list(model.state_dict().keys())
+    counts, left = dropin.swap_to_hip(model, strict=True)
+    assert left == []
+    assert counts["CLIP"] == 1 and counts["TextTransformer"] == 1 and counts["SimpleImageProjectionHead"] == 1 and counts["Embedding"] == 1
+    ours = cvnets_amd.CLIP.build_model(opts)
+    assert [n for n, _ in ours.named_modules()] == names_before
+    assert list(ours.state_dict().keys()) == keys_before
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    with pytest.raises(RuntimeError):
+        model({"image": torch.zeros(2, 3, 64, 64), "text": torch.ones(2, 77, dtype=torch.long)})

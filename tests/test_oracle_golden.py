@@ -84,6 +84,27 @@ def test_v2_oracle_matches_reference_fixture(name, wm, batch, hw):
             assert np.allclose(running[key[4:]].numpy(), gold[key], rtol=1e-5, atol=1e-6), key
 
 
+def test_clip_oracle_matches_reference_fixture():
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    gold = np.load(os.path.join(GOLD, "clip_tiny_64_b8.npz"))
+    c = json.loads(str(gold["config"]))
+    shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(GOLD, "clip_tiny_keys.json"))).items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    sd["logit_scale"] = torch.tensor(float(np.log(1.0 / 0.07)))
+    sd["image_encoder.cls_token"] = 0.02 * seeded_state_dict({"cls_token_values": shapes["image_encoder.cls_token"]}, seed=0)["cls_token_values"]
+    x = seeded_input((c["batch"], 3, c["res"], c["res"]), seed=1)
+    tok = torch.from_numpy(gold["tokens"])
+    img, txt, loss, grads, _ = orc.clip_train_step(sd, x, tok, vit_mode=c["vit_mode"], text_layers=c["text_layers"], text_heads=c["text_heads"])
+    assert np.allclose(img.numpy(), gold["image"], rtol=1e-4, atol=1e-6) and np.allclose(txt.numpy(), gold["text"], rtol=1e-4, atol=1e-6)
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5
+    names = [str(n) for n in gold["grad_names"]]
+    assert sorted(names) == sorted(grads.keys())
+    assert np.allclose(np.array([grads[k].norm().item() for k in names]), gold["grad_norm"], rtol=1e-3, atol=1e-7)
+    for key in gold.files:
+        if key.startswith("grad::"):
+            assert np.allclose(grads[key[6:]].numpy(), gold[key], rtol=1e-3, atol=1e-6), key
+
+
 def test_oracle_mha_matches_reference_fixture():
     gold = np.load(os.path.join(GOLD, "mha_cases.npz"))
     for idx in range(4):

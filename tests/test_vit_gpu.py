@@ -42,7 +42,7 @@ def _step(model, x, y):
     logits = model(x)
     loss = F.cross_entropy(logits.float(), y, label_smoothing=0.1)
     loss.backward()
-    return logits.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+    return logits.detach().float().cpu(), float(loss.detach()), {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
 
 
 @pytest.mark.parametrize("name,mode,batch,res", CASES)
@@ -188,7 +188,7 @@ def test_patch_conv_dx_and_dw(dtype, cfg):
     B, Cin, Cout, H, W, k = cfg
     cvnets_amd.set_compute_dtype(dtype)
     opts = default_opts()
-    layer = ConvLayer2d(opts, Cin, Cout, k, stride=k, bias=True, use_norm=False, use_act=False).cuda()
+    layer = ConvLayer2d(opts, Cin, Cout, k, stride=k, padding=(0, 0), bias=True, use_norm=False, use_act=False).cuda()
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B, Cin, H, W, generator=g)
     dy = torch.randn(B, Cout, H // k, W // k, generator=g)

@@ -149,7 +149,8 @@ __global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, int act, size_t rows, int C, float* __restrict__ part) {
+                                                        const float* __restrict__ invstd, int act, size_t rows, int C, float* __restrict__ part,
+                                                        size_t ld) {
   __shared__ float red[4096];
   const int cgs = C / 8;
   const int RL = 256 / cgs;
@@ -170,12 +171,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
     for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += 2 * step) {  // two rows in flight per thread
       const size_t r2 = r + step;
       const bool two = r2 < rows;
-      V8<T> xa = v8_load<T>(x + r * C + ci * 8);
-      V8<T> xb = two ? v8_load<T>(x + r2 * C + ci * 8) : v8_zero<T>();
+      V8<T> xa = v8_load<T>(x + r * ld + ci * 8);
+      V8<T> xb = two ? v8_load<T>(x + r2 * ld + ci * 8) : v8_zero<T>();
       V8<T> da = v8_zero<T>(), db = v8_zero<T>();
       if (MODE == 1) {
-        da = v8_load<T>(dout + r * C + ci * 8);
-        if (two) db = v8_load<T>(dout + r2 * C + ci * 8);
+        da = v8_load<T>(dout + r * ld + ci * 8);
+        if (two) db = v8_load<T>(dout + r2 * ld + ci * 8);
       }
       float xf[8], xg[8];
       v8_unpack(xa, xf);
@@ -636,9 +637,17 @@ extern "C" int cvh_cast_to_f32(int dtype, const void* in, float* out, long long 
   return 0;
 }
 
-extern "C" int cvh_colreduce_rows(long long rows, int C) {
+// widest column block (multiple of 8, divides C, <= 2048) the 256-thread column kernels handle in one launch
+static inline int col_block(int C) {
+  if (C <= 2048) return C;
+  for (int cb = 2048; cb >= 8; cb -= 8)
+    if (C % cb == 0) return cb;
+  return -1;
+}
+extern "C" int cvh_colreduce_rows(long long rows, int C_full) {
   // number of partial rows (gridDim.x) the column-reduction kernels write
-  if (C % 8 || C > 2048 || C <= 0) return -2;
+  if (C_full % 8 || C_full <= 0) return -2;
+  const int C = col_block(C_full);
   const int RL = 256 / (C / 8);
   long long g = (rows + (long long)RL * 8 - 1) / ((long long)RL * 8);
   if (g > 512) g = 512;
@@ -647,19 +656,23 @@ extern "C" int cvh_colreduce_rows(long long rows, int C) {
 }
 
 extern "C" int cvh_bn_stats(int dtype, const void* x, long long rows, int C, float* part, void* stream) {
+  if (C > 2048) return -2;
   int g = cvh_colreduce_rows(rows, C);
   if (g < 0) return g;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 0>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part);)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 0>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part, (size_t)C);)
   CVH_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, int accumulate, void* stream) {
   int g = cvh_colreduce_rows(rows, C);
   if (g < 0) return g;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, C, part);)
-  CVH_CHECK_LAUNCH();
-  // the plain sums live in the first C entries of each 2C-wide partial row
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, g, 2 * C, C, out, scale, accumulate);
+  const int Cb = col_block(C);  // wide matrices (ViT-B FFN: 3072 columns) go block of columns by block of columns
+  for (int c0 = 0; c0 < C; c0 += Cb) {
+    float* pb = part + (size_t)(c0 / Cb) * g * 2 * Cb;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x + c0, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, Cb, pb, (size_t)C);)
+    // the plain sums live in the first Cb entries of each 2Cb-wide partial row
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((Cb + 15) / 16), dim3(1024), 0, (hipStream_t)stream, pb, g, 2 * Cb, Cb, out + c0, scale, accumulate);
+  }
   CVH_CHECK_LAUNCH();
   return 0;
 }
@@ -692,9 +705,10 @@ extern "C" int cvh_bn_apply(int dtype, const void* x, const float* scale, const 
 }
 extern "C" int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, int act, long long rows, int C, float* part, void* stream) {
+  if (C > 2048) return -2;
   int g = cvh_colreduce_rows(rows, C);
   if (g < 0) return g;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 1>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dout, scale, shift, mean, invstd, act, (size_t)rows, C, part);)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 1>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dout, scale, shift, mean, invstd, act, (size_t)rows, C, part, (size_t)C);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -303,6 +303,9 @@ def _unit_coeffs(C, device):
 
 def _act_backward(pre: torch.Tensor, dout: torch.Tensor, act: int, rows: int, C: int) -> torch.Tensor:
     """dpre = dout * act'(pre)  (BatchNorm-backward apply kernel with identity normalisation)."""
+    if C > 2048:  # purely elementwise with unit coefficients: view the matrix with narrower rows (ViT-B FFN: 3072 -> 2 x 1536)
+        Cb = next(c for c in range(2048, 7, -8) if C % c == 0)
+        rows, C = rows * (C // Cb), Cb
     ones, zeros = _unit_coeffs(C, pre.device)
     dx = torch.empty_like(dout)
     _lib.call("cvh_bn_bwd_apply", _dt(pre), _p(pre), _p(dout), _p(ones), _p(zeros), act, _p(ones), _p(zeros), _p(zeros), _p(dx), rows, C,

@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""Throughput of the widened SURVEY §8 rows (a12 ViT, a13 MobileViTv2, a14 CLIP) measured exactly like bench.py measures the
+headline MobileViT-S config: synthetic data resident in HBM, zero_grad + fwd + loss + bwd + fused AdamW captured in one hipGraph,
+K timed replays between HIP events.  One JSON line per model, with the roofline that bounds it:
+
+  python tools/bench_models.py --models vit_base,mobilevitv2,clip [--steps 10 --warmup 3]
+
+These are self-measurement lines for DESIGN.md / profiles/, not the driver's bench contract (bench.py)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+sys.path.insert(0, REPO)
+
+HBM_PEAK, MFMA_PEAK = 8.0e12, 2.5e15
+# (fwd+bwd GFLOP/img, ideal fwd+bwd MB/img, binding roof)
+ALGO = {"vit_base": (106.25, 190.9, "mfma"), "vit_tiny": (None, None, "mfma"), "mobilevitv2": (24.46, 362.6, "hbm"), "clip": (124.0, None, "mfma"),
+        "mobilevit_s": (12.0, 176.1, "hbm")}
+
+
+def build(name, batch, dev):
+    import cvnets_amd
+    from oracle.weights import seeded_caption_tokens
+
+    if name in ("vit_base", "vit_tiny"):
+        m = cvnets_amd.build_vit(name.split("_")[1], **{"model.classification.vit.dropout": 0.2 if name == "vit_base" else 0.0}).to(dev).train()
+        x = torch.randn(batch, 3, 224, 224, device=dev)
+        y = torch.randint(0, 1000, (batch,), device=dev)
+        return m, lambda: F.cross_entropy(m(x).float(), y, label_smoothing=0.1), "224x224"
+    if name == "mobilevitv2":
+        m = cvnets_amd.build_mobilevit_v2(1.0).to(dev).train()
+        x = torch.randn(batch, 3, 384, 384, device=dev)
+        y = torch.randint(0, 1000, (batch,), device=dev)
+        return m, lambda: F.cross_entropy(m(x).float(), y, label_smoothing=0.1), "384x384 width 1.0"
+    if name == "mobilevit_s":
+        m = cvnets_amd.build_mobilevit("small").to(dev).train()
+        x = torch.randn(batch, 3, 256, 256, device=dev)
+        y = torch.randint(0, 1000, (batch,), device=dev)
+        return m, lambda: F.cross_entropy(m(x).float(), y, label_smoothing=0.1), "256x256"
+    if name == "clip":
+        from cvnets_amd.layers import default_opts
+        m = cvnets_amd.build_clip().to(dev).train()
+        loss_fn = cvnets_amd.ContrastiveLossClip(default_opts()).train()
+        x = torch.randn(batch, 3, 224, 224, device=dev)
+        tok = seeded_caption_tokens(batch, 77, 49408, seed=0).to(dev)
+        return m, lambda: loss_fn(None, m({"image": x, "text": tok}))["total_loss"], "ViT-B/16 224x224 + 12x512 text, ctx 77"
+    raise SystemExit(f"unknown model {name}")
+
+
+def run(name, batch, steps, warmup, dtype, use_graph):
+    import cvnets_amd
+    from cvnets_amd.ddp import DistributedDataParallel
+
+    dev = torch.device("cuda", 0)
+    cvnets_amd.set_compute_dtype(dtype)
+    torch.manual_seed(1234)
+    model, loss_of, desc = build(name, batch, dev)
+    ddp = DistributedDataParallel(model, bucket_cap_mb=25.0, broadcast_buffers=False)
+    ddp.hooks_enabled = False
+    cvnets_amd.ops.set_inplace_param_grads(True)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, fused=True, capturable=True)
+
+    def one():
+        ddp.zero_grad()
+        loss = loss_of()
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            loss = one()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph, err = None, None
+    if use_graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = one()
+            graph = g
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"[:200]
+            torch.cuda.synchronize()
+    step = graph.replay if graph is not None else one
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ips = batch * steps / wall
+    gf, mb, bound = ALGO[name]
+    out = {"model": name, "workload": f"{desc}, {batch} img/GPU", "dtype": str(dtype).split(".")[-1], "images_per_sec": round(ips, 1),
+           "ms_per_step": round(wall * 1e3 / steps, 3), "gpu_ms_per_step_hip_events": round(e0.elapsed_time(e1) / steps, 3), "hipgraph": graph is not None,
+           "loss": round(float(loss), 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "bound": bound}
+    if gf:
+        out["mfma_frac"] = round(gf * 1e9 * ips / MFMA_PEAK, 4)
+        out["achieved_TFLOPs"] = round(gf * 1e9 * ips / 1e12, 1)
+    if mb:
+        out["hbm_frac"] = round(mb * 1e6 * ips / HBM_PEAK, 4)
+    if err:
+        out["hipgraph_error"] = err
+    cvnets_amd.ops.set_inplace_param_grads(False)
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--models", default="vit_base,mobilevitv2,clip")
+    ap.add_argument("--batch", default="vit_base=128,vit_tiny=256,mobilevitv2=128,clip=128,mobilevit_s=128")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+    batches = dict(kv.split("=") for kv in a.batch.split(","))
+    for name in a.models.split(","):
+        try:
+            print(json.dumps(run(name, int(batches[name]), a.steps, a.warmup, torch.bfloat16 if a.dtype == "bf16" else torch.float32, not a.no_graph)), flush=True)
+        except Exception as e:  # keep going: one model failing must not hide the others
+            print(json.dumps({"model": name, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
+        torch.cuda.empty_cache()

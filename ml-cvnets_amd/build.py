@@ -19,7 +19,7 @@ INC = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcvnets_hip.so")
-SOURCES = ["gemm.hip", "elementwise.hip", "dwconv.hip", "layernorm.hip", "attention.hip", "tokens.hip", "linattn.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "elementwise.hip", "dwconv.hip", "layernorm.hip", "attention.hip", "tokens.hip", "linattn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-I" + CSRC, "-I" + INC]
 
@@ -40,7 +40,7 @@ def _stale(obj, deps):
 
 def compile_one(src, force, verbose):
     obj = os.path.join(BUILD, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.hpp"), os.path.join(INC, "cvnets_hip.h"), __file__]
+    deps = [os.path.join(CSRC, src), os.path.join(INC, "cvnets_hip.h"), __file__] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
     if not force and not _stale(obj, deps):
         return obj, 0.0, ""
     t0 = time.time()

@@ -83,16 +83,74 @@ __device__ __forceinline__ void stage_rows(T* lds, int pitch, const T* g, int ld
   }
 }
 
+// Register-prefetched staging of an [NROWS x CP] tile (rows picked by an index list, first c columns valid, the rest zero) by NT
+// threads.  `load` only ISSUES the global reads (into registers) so it can be placed a whole tile ahead of its use and overlap
+// with the MFMA / softmax work of the current tile; `store` writes the registers (optionally scaled) into LDS.  The plain
+// stage_rows above is load -> wait -> store per element group, which serialises one HBM round trip per loop iteration.
+template <typename T, int CP, int VEC, int NROWS, int NT>
+struct TileStager {
+  static constexpr int CH = CP / VEC;
+  static constexpr int IT = (NROWS * CH + NT - 1) / NT;
+  V4<T> q[VEC == 4 ? IT : 1];
+  T e[VEC == 4 ? 1 : IT][VEC == 4 ? 1 : VEC];
+
+  __device__ __forceinline__ void load(const T* __restrict__ g, int ld, int col0, const int* rowidx, int nrows, int c, int tid) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CH, cc = (idx - r * CH) * VEC;
+      int ri = -1;
+      if (idx < NROWS * CH && r < nrows && cc < c) ri = rowidx[r];
+      if constexpr (VEC == 4) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        v4_pack(z, q[it]);
+        if (ri >= 0) q[it] = v4_load<T>(g + (size_t)ri * ld + col0 + cc);
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) e[it][k] = (ri >= 0) ? g[(size_t)ri * ld + col0 + cc + k] : from_f<T>(0.f);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(T* lds, int pitch, float scale, int tid) const {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      if (idx >= NROWS * CH) continue;
+      const int r = idx / CH, cc = (idx - r * CH) * VEC;
+      if constexpr (VEC == 4) {
+        V4<T> v = q[it];
+        if (scale != 1.0f) {
+          float f[4];
+          v4_unpack(v, f);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[k] *= scale;
+          v4_pack(f, v);
+        }
+        v4_store<T>(lds + r * pitch + cc, v);
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) lds[r * pitch + cc + k] = (scale != 1.0f) ? from_f<T>(to_f<T>(e[it][k]) * scale) : e[it][k];
+      }
+    }
+  }
+};
+
 // operand fragment read "down the rows" of a row-major [k][n] LDS tile (the transposed operand):
 // element j = tile[k0 + 8*(lane>>5) + j][col0 + (lane&31)]
+// bf16: two gfx950 LDS transpose reads (ds_read_b64_tr_b16).  Inside a 16-lane group lane i = 4r + q supplies the address of 4
+// contiguous elements of block row r (columns 4q..4q+3) and receives COLUMN i of that 4 x 16 block, i.e. 4 consecutive k of one n —
+// exactly half an MFMA operand.  Needs 8-byte aligned addresses: pitch % 4 == 0, col0 % 4 == 0 (measured on MI355X with
+// tools/experiments/tr_probe.hip).  Replaces 8 ds_read_u16 + 4 pack VALU ops per fragment.
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Frag<bf16_t> lds_frag_strided(const bf16_t* tile, int pitch, int k0, int col0, int lane) {
-  const uint16_t* p = reinterpret_cast<const uint16_t*>(tile) + (k0 + 8 * (lane >> 5)) * pitch + col0 + (lane & 31);
-  uint32_t w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)p[(2 * i) * pitch] | ((uint32_t)p[(2 * i + 1) * pitch] << 16);
+  const int i = lane & 15;
+  const bf16_t* p = tile + (k0 + 8 * (lane >> 5) + (i >> 2)) * pitch + col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
+  const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + 4 * pitch));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   Frag<bf16_t> f;
-  uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
-  f.v = __builtin_bit_cast(bf16x8_t, u);
+  f.v = __builtin_bit_cast(bf16x8_t, both);
   return f;
 }
 __device__ __forceinline__ Frag<float> lds_frag_strided(const float* tile, int pitch, int k0, int col0, int lane) {
@@ -143,7 +201,7 @@ static size_t carve_bytes(size_t elems, size_t esz) { return (elems * esz + 15) 
 // =============================================================================================
 template <typename T, int CP, int VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
-  constexpr int KB = 64;
+  constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int PP = lds_pitch<T>(KB);
   constexpr int NFC = CP / 32;
@@ -173,7 +231,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
-  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane, 64);
+  TileStager<T, CP, VEC, KB, 64 * NW> kst, vst;
+  auto load_kv = [&](int kv0) {
+    const int nk = min(KB, p.S - kv0);
+    kst.load(qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, tid);
+    vst.load(qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, tid);
+  };
+  {
+    TileStager<T, CP, VEC, 32, 64> qst;
+    qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
+    load_kv(0);  // first K/V tile requested together with Q
+    qst.store(Qs, PQ, p.scaling, lane);
+  }
 
   const int my_q = q0 + (lane & 31);
   float m_run = -1e30f, l_run = 0.f;
@@ -184,19 +253,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
     if (p.causal && kv0 > q0_last + 31) break;  // tile entirely in the future of every query of the workgroup
     __syncthreads();                             // previous tile's K/V (and this wave's P) fully consumed
-    {
-      const int nk = min(KB, p.S - kv0);
-      // rows beyond the sequence are zero-filled through a negative index trick: stage_rows reads rowidx[r]
-      stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
-      stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
-      if (nk < KB) {  // zero the tail rows of a partial tile (V rows feed the MFMA k-dimension)
-        for (int idx = tid; idx < (KB - nk) * PQ; idx += 64 * NW) {
-          Ks[nk * PQ + idx] = from_f<T>(0.f);
-          Vs[nk * PQ + idx] = from_f<T>(0.f);
-        }
-      }
-    }
+    kst.store(Ks, PQ, 1.0f, tid);                // rows past the sequence end arrive as zeros (V rows feed the MFMA k-dimension)
+    vst.store(Vs, PQ, 1.0f, tid);
+    if (kv0 + KB < p.S) load_kv(kv0 + KB);       // next tile's HBM reads fly under this tile's MFMA + softmax
     __syncthreads();
+    const bool full_tile = !p.causal && p.kpm == nullptr && kv0 + KB <= p.S;  // workgroup-uniform: no per-element visibility tests
 
     // S^T[key][q] = sum_c K[key][c] * Qs[q][c]
     f32x16_t sacc[KB / 32];
@@ -217,8 +278,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
     for (int f = 0; f < KB / 32; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + f * 32 + acc_row(r, lane);
-        float v = key_visible(p, s, key, my_q) ? round_to<T>(sacc[f][r]) : -INFINITY;
+        float v = sacc[f][r];
+        if (!full_tile) {
+          const int key = kv0 + f * 32 + acc_row(r, lane);
+          if (!key_visible(p, s, key, my_q)) v = -INFINITY;
+        }
         sv[f][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -308,7 +372,7 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restric
 // =============================================================================================
 template <typename T, int CP, int VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int KB = 64;
+  constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int PP = lds_pitch<T>(KB);
   constexpr int NFC = CP / 32;
@@ -341,8 +405,20 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
-  stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq, 32, p.c, p.scaling, lane, 64);
-  stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq, 32, p.c, 1.0f, lane, 64);
+  TileStager<T, CP, VEC, KB, 64 * NW> kst, vst;
+  auto load_kv = [&](int kv0) {
+    const int nk = min(KB, p.S - kv0);
+    kst.load(qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, tid);
+    vst.load(qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, tid);
+  };
+  {
+    TileStager<T, CP, VEC, 32, 64> qst, dst;
+    qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
+    dst.load(dout, p.d, head * p.c, rq, 32, p.c, lane);
+    load_kv(0);
+    qst.store(Qs, PQ, p.scaling, lane);
+    dst.store(dOs, PQ, 1.0f, lane);
+  }
 
   const int my_q = q0 + (lane & 31);
   const bool q_ok = my_q < p.S;
@@ -356,18 +432,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
     if (p.causal && kv0 > q0_last + 31) break;
     __syncthreads();
-    {
-      const int nk = min(KB, p.S - kv0);
-      stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
-      stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, 1.0f, tid, 64 * NW);
-      if (nk < KB) {
-        for (int idx = tid; idx < (KB - nk) * PQ; idx += 64 * NW) {
-          Ks[nk * PQ + idx] = from_f<T>(0.f);
-          Vs[nk * PQ + idx] = from_f<T>(0.f);
-        }
-      }
-    }
+    kst.store(Ks, PQ, 1.0f, tid);
+    vst.store(Vs, PQ, 1.0f, tid);
+    if (kv0 + KB < p.S) load_kv(kv0 + KB);
     __syncthreads();
+    const bool full_tile = !p.causal && p.kpm == nullptr && kv0 + KB <= p.S;
 
     f32x16_t sacc[KB / 32], dpacc[KB / 32];
 #pragma unroll
@@ -389,13 +458,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + f * 32 + acc_row(r, lane);
-        float v = 0.f;
-        if (q_ok && key_visible(p, s, key, my_q)) {
-          const float pv = __expf(round_to<T>(sacc[f][r]) - lse);
-          v = pv * (dpacc[f][r] - dsum);
+        bool vis = true;  // (rows of absent queries are computed but never stored)
+        if (!full_tile) {
+          const int key = kv0 + f * 32 + acc_row(r, lane);
+          vis = q_ok && key_visible(p, s, key, my_q);
         }
-        ds[r] = v;
+        ds[r] = vis ? __expf(sacc[f][r] - lse) * (dpacc[f][r] - dsum) : 0.f;
       }
       store_acc_transposed<T>(dSs, PP, f * 32, ds, lane);
     }
@@ -474,33 +542,46 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   for (int i = tid; i < p.S; i += 64 * NW) rq[i] = seq_row(p.map, s, i);
   if (lane < 32) rk[lane] = (k0 + lane < p.S) ? seq_row(p.map, s, k0 + lane) : -1;
   __syncthreads();
-  stage_rows<T, CP, VEC>(Ks, PQ, qkv, ld, p.d + head * p.c, rk, 32, p.c, 1.0f, lane, 64);
-  stage_rows<T, CP, VEC>(Vs, PQ, qkv, ld, 2 * p.d + head * p.c, rk, 32, p.c, 1.0f, lane, 64);
+  TileStager<T, CP, VEC, QB, 64 * NW> qst, dst;
+  float lse_n = 0.f, dsum_n = 0.f;  // softmax statistics of the prefetched query tile
+  auto load_q = [&](int qb0) {
+    const int nq = min(QB, p.S - qb0);
+    qst.load(qkv, ld, head * p.c, rq + qb0, nq, p.c, tid);
+    dst.load(dout, p.d, head * p.c, rq + qb0, nq, p.c, tid);
+    const int q = qb0 + (lane & 31);
+    const size_t si = ((size_t)s * p.h + head) * p.S + (q < p.S ? q : 0);
+    lse_n = p.lse[si];
+    dsum_n = p.dsum[si];
+  };
+  auto q_block_skipped = [&](int qb0) { return p.causal && qb0 + QB - 1 < k0_first; };  // all its queries precede every key of the workgroup
+  int qb_next = 0;
+  while (qb_next < p.S && q_block_skipped(qb_next)) qb_next += QB;
+  {
+    TileStager<T, CP, VEC, 32, 64> kst, vst;
+    kst.load(qkv, ld, p.d + head * p.c, rk, 32, p.c, lane);
+    vst.load(qkv, ld, 2 * p.d + head * p.c, rk, 32, p.c, lane);
+    if (qb_next < p.S) load_q(qb_next);
+    kst.store(Ks, PQ, 1.0f, lane);
+    vst.store(Vs, PQ, 1.0f, lane);
+  }
 
   f32x16_t dkacc[NFC], dvacc[NFC];
 #pragma unroll
   for (int f = 0; f < NFC; ++f) { dkacc[f] = acc_zero(); dvacc[f] = acc_zero(); }
 
-  for (int qb0 = 0; qb0 < p.S; qb0 += QB) {
-    if (p.causal && qb0 + QB - 1 < k0_first) continue;  // all queries of this block precede every key of the workgroup
+  while (qb_next < p.S) {
+    const int qb0 = qb_next;
     __syncthreads();
-    {
-      const int nq = min(QB, p.S - qb0);
-      stage_rows<T, CP, VEC>(Qs, PQ, qkv, ld, head * p.c, rq + qb0, nq, p.c, p.scaling, tid, 64 * NW);
-      stage_rows<T, CP, VEC>(dOs, PQ, dout, p.d, head * p.c, rq + qb0, nq, p.c, 1.0f, tid, 64 * NW);
-      if (nq < QB) {
-        for (int idx = tid; idx < (QB - nq) * PQ; idx += 64 * NW) {
-          Qs[nq * PQ + idx] = from_f<T>(0.f);
-          dOs[nq * PQ + idx] = from_f<T>(0.f);
-        }
-      }
-    }
+    qst.store(Qs, PQ, p.scaling, tid);
+    dst.store(dOs, PQ, 1.0f, tid);
+    const float lse = lse_n, dsum = dsum_n;
+    qb_next = qb0 + QB;
+    if (qb_next < p.S) load_q(qb_next);  // next query tile (+ its statistics) in flight during this tile's math
     __syncthreads();
 
     const int my_q = qb0 + (lane & 31);
     const bool q_ok = my_q < p.S;
-    const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
-    const float lse = p.lse[sidx], dsum = p.dsum[sidx];
+    const bool full_tile = !p.causal && p.kpm == nullptr && qb0 + QB <= p.S && k0 + 32 <= p.S;
 
     f32x16_t sacc = acc_zero(), dpacc = acc_zero();
 #pragma unroll
@@ -512,20 +593,20 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
       mma32(sacc, ak, bq);
       mma32(dpacc, av, bd);
     }
-    float pt[16], dst[16];
+    float pt[16], dsv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = k0 + acc_row(r, lane);
-      float pv = 0.f, dv = 0.f;
-      if (q_ok && key_visible(p, s, key, my_q)) {
-        pv = __expf(round_to<T>(sacc[r]) - lse);
-        dv = pv * (dpacc[r] - dsum);
+      bool vis = true;
+      if (!full_tile) {
+        const int key = k0 + acc_row(r, lane);
+        vis = q_ok && key_visible(p, s, key, my_q);
       }
+      const float pv = vis ? __expf(sacc[r] - lse) : 0.f;
       pt[r] = pv;
-      dst[r] = dv;
+      dsv[r] = pv * (dpacc[r] - dsum);
     }
     store_acc_natural<T>(PTs, PT, 0, 0, pt, lane);    // PTs[key][q]
-    store_acc_natural<T>(dSTs, PT, 0, 0, dst, lane);  // dSTs[key][q]
+    store_acc_natural<T>(dSTs, PT, 0, 0, dsv, lane);  // dSTs[key][q]
     __syncthreads();
     // dV[key][c] += sum_q P^T[key][q] dO[q][c] ;  dK[key][c] += sum_q dS^T[key][q] Qs[q][c]
 #pragma unroll

@@ -13,29 +13,7 @@
 #include "common.hpp"
 #include "cvnets_hip.h"
 
-struct ConvGemmParams {
-  const void* src1;
-  const void* src2;
-  int C1, C2;
-  const void* wgt;
-  void* out;
-  int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
-  int M, N, Ktot;
-  const float* bias;
-  int act;
-  void* save_pre;
-  const void* actgrad_aux;
-  int actgrad_act;
-  const void* residual;
-  float drop_p;
-  const unsigned long long* seed;
-  unsigned int stream_id;
-  float* stats_part;
-  int m_tiles;
-  // output scatter (dX of a non-overlapping strided conv, kernel == stride, pad 0): GEMM row m = (b, ho, wo) of the sc_Ho x sc_Wo
-  // map, column n = (kh, kw, c) -> out[b][ho*sc_s + kh][wo*sc_s + kw][c] of a sc_H x sc_W x sc_C map.  sc_s == 0: plain [M][N] output.
-  int sc_s, sc_KW, sc_C, sc_H, sc_W, sc_Ho, sc_Wo;
-};
+#include "gemm_params.hpp"
 
 // staging-group decomposition of the NF accumulator fragments of a wave: groups of 4 / 2 / 1 fragments so that the
 // number of 8-wide column chunks per staged row (16 / 8 / 4) divides the wave size
@@ -596,6 +574,7 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   p.sc_s = 0; p.sc_KW = p.sc_C = p.sc_H = p.sc_W = p.sc_Ho = p.sc_Wo = 0;
   if (p.M <= 0 || N <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16 && gemm_big_eligible(p)) return launch_gemm_big(p, st);  // transformer-sized linears (ViT-B / CLIP)
   const int nf = choose_nf(N);
   const bool bk64 = p.Ktot >= 64;
   if (dtype == CVH_DT_BF16) {

@@ -1,0 +1,168 @@
+// Large-tile bf16 NT GEMM for transformer-sized linear layers (ViT-B / CLIP token GEMMs: M = B*S >= 2048 rows, K and N in the
+// hundreds to thousands):   out[m][n] = epilogue( sum_k A[m][k] * Wp[n][k] ),  A = activations [M][K], Wp = packed weights [N][K].
+// (dX of a linear layer is the same product with the transposed weight pack, so it runs here too.)
+//
+//   * 128 x 128 output tile per workgroup, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA 32x32x16 accumulators;
+//   * K step 64; both operand tiles go HBM/L2 -> LDS directly (global_load_lds, 16 B per lane, no staging VGPRs), double
+//     buffered: the loads of K step t+1 are in flight while step t is on the matrix cores, one barrier per K step;
+//   * LDS image = 128-byte rows (64 bf16) with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7: the direct-to-LDS write
+//     is lane-linear, so the swizzle is applied by choosing WHICH global chunk each lane fetches (same 128-B line -> coalescing
+//     unchanged), and the ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct bank groups;
+//   * XCD-contiguous tile order: consecutive workgroups on one XCD walk the N tiles of the same A row panel (A panel and the
+//     whole weight matrix stay in that XCD's L2);
+//   * epilogue identical in semantics to conv_gemm's (bias -> save_pre -> activation -> dropout -> residual), staged through
+//     LDS so every store is a full 128-byte row segment.
+#include "common.hpp"
+#include "gemm_params.hpp"
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 16 KB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int STG_PITCH = 64 + 8;            // bf16 elements per staged output row (64 columns + 16 B pad)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+__device__ __forceinline__ Frag<bf16_t> frag_swz(const unsigned char* tile, int row, int chunk) {
+  const unsigned char* p = tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8_t*>(p);
+  return f;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ONE LDS object: 2 x (A tile | B tile); reused by the epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int K = p.Ktot, N = p.N, M = p.M;
+  const int NT = N / BN;
+  const int total = p.m_tiles * NT;
+  const int L = xcd_chunk_id(blockIdx.x, total);
+  const int mt = L / NT, nt = L - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.src1);
+  const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(p.wgt);
+
+  // this lane's 4 + 4 chunks per K step: wave-instruction i = wave*4 + j covers tile rows [8i, 8i+8), lane -> (row, LDS slot)
+  const bf16_t* ga[4];
+  const bf16_t* gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);  // global chunk that belongs in LDS slot (lane & 7) of this row
+    int am = m0 + row;
+    if (am > M - 1) am = M - 1;  // rows past M: read a valid row, the result is never stored
+    ga[j] = A + (size_t)am * K + c * 8;
+    gb[j] = Wp + (size_t)(n0 + row) * K + c * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    unsigned char* a_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024;
+    unsigned char* b_dst = a_dst + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(ga[j] + kt * BK, a_dst + j * 1024);
+      glds16(gb[j] + kt * BK, b_dst + j * 1024);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
+
+  const int KT = K / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+    const unsigned char* At = smem + buf * BUF_BYTES;
+    const unsigned char* Bt = At + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int chunk = 2 * kk + (lane >> 5);
+      Frag<bf16_t> a0 = frag_swz(At, wr * 64 + (lane & 31), chunk);
+      Frag<bf16_t> a1 = frag_swz(At, wr * 64 + 32 + (lane & 31), chunk);
+      Frag<bf16_t> b0 = frag_swz(Bt, wc * 64 + (lane & 31), chunk);
+      Frag<bf16_t> b1 = frag_swz(Bt, wc * 64 + 32 + (lane & 31), chunk);
+      mma32(acc[0][0], a0, b0);
+      mma32(acc[0][1], a0, b1);
+      mma32(acc[1][0], a1, b0);
+      mma32(acc[1][1], a1, b1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // (a) everyone is done reading `buf`, (b) tile kt+1 has landed in buf^1 for all waves
+  }
+
+  // ---- epilogue: accumulators (+bias) -> per-wave LDS staging -> coalesced rows with the fused ops ----
+  bf16_t* stg = reinterpret_cast<bf16_t*>(smem) + wave * (64 * STG_PITCH);
+  unsigned long long seed = 0;
+  if (p.drop_p > 0.f) seed = *p.seed;
+  const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int n = n0 + wc * 64 + tj * 32 + (lane & 31);
+    const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stg[(ti * 32 + acc_row(r, lane)) * STG_PITCH + tj * 32 + (lane & 31)] = from_f<bf16_t>(acc[ti][tj][r] + bias);
+  }
+  wave_lds_sync();
+  const int ch = lane & 7;
+  const int ncol = n0 + wc * 64 + ch * 8;
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 8 + (lane >> 3);
+    const int m = m0 + wr * 64 + row;
+    if (m < M) {
+      const size_t o = (size_t)m * N + ncol;
+      V8<bf16_t> pv = v8_load<bf16_t>(stg + row * STG_PITCH + ch * 8);
+      if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
+      float v[8];
+      v8_unpack(pv, v);
+      if (p.act != CVH_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], p.act);
+      }
+      if (p.drop_p > 0.f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(seed, p.stream_id, o + j, p.drop_p, inv_keep);
+      }
+      if (p.residual) {
+        float rr[8];
+        v8_unpack(v8_load<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + o), rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+      }
+      V8<bf16_t> ov;
+      v8_pack(v, ov);
+      v8_store<bf16_t>(out + o, ov);
+    }
+  }
+}
+
+bool gemm_big_eligible(const ConvGemmParams& p) {
+  if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
+  const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
+  return linear && p.M >= 2048 && p.N >= 256 && (p.N % BN) == 0 && p.Ktot >= 256 && (p.Ktot % BK) == 0 && p.stats_part == nullptr &&
+         p.actgrad_aux == nullptr && p.sc_s == 0;
+}
+
+int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
+  ConvGemmParams p = p0;
+  p.m_tiles = (p.M + BM - 1) / BM;
+  const int total = p.m_tiles * (p.N / BN);
+  constexpr int smem = 2 * BUF_BYTES;  // 64 KB: two workgroups per CU
+  hipLaunchKernelGGL(gemm_nt128_kernel, dim3(total), dim3(256), smem, st, p);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

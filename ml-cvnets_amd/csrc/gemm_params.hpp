@@ -1,0 +1,31 @@
+// Parameter block shared by the implicit-GEMM kernels (gemm.hip) and the large-tile linear kernel (gemm_big.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct ConvGemmParams {
+  const void* src1;
+  const void* src2;
+  int C1, C2;
+  const void* wgt;
+  void* out;
+  int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
+  int M, N, Ktot;
+  const float* bias;
+  int act;
+  void* save_pre;
+  const void* actgrad_aux;
+  int actgrad_act;
+  const void* residual;
+  float drop_p;
+  const unsigned long long* seed;
+  unsigned int stream_id;
+  float* stats_part;
+  int m_tiles;
+  // output scatter (dX of a non-overlapping strided conv, kernel == stride, pad 0): GEMM row m = (b, ho, wo) of the sc_Ho x sc_Wo
+  // map, column n = (kh, kw, c) -> out[b][ho*sc_s + kh][wo*sc_s + kw][c] of a sc_H x sc_W x sc_C map.  sc_s == 0: plain [M][N] output.
+  int sc_s, sc_KW, sc_C, sc_H, sc_W, sc_Ho, sc_Wo;
+};
+
+// gemm_big.hip
+bool gemm_big_eligible(const ConvGemmParams& p);
+int launch_gemm_big(const ConvGemmParams& p, hipStream_t st);

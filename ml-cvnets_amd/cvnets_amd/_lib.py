@@ -10,7 +10,9 @@ import os
 from ctypes import c_double, c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvnets_hip.so")
+# CVNETS_HIP_LIB: developer override used for in-process/same-box A/B runs of two builds of the SAME ABI (box-to-box variance on the
+# pool is larger than most kernel changes); the shipped path is always the in-tree library.
+LIB_PATH = os.environ.get("CVNETS_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libcvnets_hip.so")
 
 P = c_void_p
 I = c_int

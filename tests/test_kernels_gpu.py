@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import check, nhwc, rel_err
+from util import check, l2_err, nhwc, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +61,9 @@ def test_gemm_asymmetric(ops, dtype):
 
 
 LINEAR_SHAPES = [(128, 16, 64), (1000, 64, 32), (257, 144, 432), (4096, 288, 144), (64, 640, 1000), (513, 240, 720), (300, 96, 96),
-                 (77, 32, 128), (20000, 32, 128), (130, 384, 192)]
+                 (77, 32, 128), (20000, 32, 128), (130, 384, 192),
+                 # transformer-sized linears: bf16 takes the 128x128 direct-to-LDS kernel (csrc/gemm_big.hip) for fwd AND dX
+                 (2500, 768, 768), (2048, 256, 1024), (4100, 3072, 768), (3000, 512, 2304)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -351,6 +353,28 @@ def test_pool_and_dropout(ops, dtype):
     assert torch.equal(gd != 0, d1 != 0)
     d2 = ops.dropout(t, p, True)
     assert not torch.equal(d1 != 0, d2 != 0)  # different call site id -> different mask
+
+
+def test_big_gemm_matches_generic_kernel(ops):
+    """the large-tile kernel and the generic implicit-GEMM kernel must agree on the same bf16 problem (identical fp32 accumulate order
+    per 64-wide K step is NOT guaranteed, so: tight tolerance, not bit equality), including the dropout mask (same element indexing)."""
+    from cvnets_amd import _lib
+
+    M, K, N = 2304, 768, 1536
+    x = _rand(M, K, seed=11).to(torch.bfloat16)
+    w = _rand(N, K, seed=12, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=13, scale=0.1)
+    res = _rand(M, N, seed=14).to(torch.bfloat16)
+    outs = []
+    for knob in (1, 0):
+        _lib.call("cvh_set_tuning", 5, knob)
+        try:
+            y = ops.LinearAct.apply(x, w, b, res, (2, 0.1, 77))
+            outs.append(y.float())
+        finally:
+            _lib.call("cvh_set_tuning", 5, 1)
+    assert torch.equal(outs[0] == res.float(), outs[1] == res.float())  # identical dropout masks
+    assert l2_err(outs[0], outs[1]) < 2e-3
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,6 +1,7 @@
 import csv,re,collections,sys
 d=sys.argv[1]
-rows=list(csv.DictReader(open(f'{d}/bench_kernel_trace.csv')))
+import glob
+rows=list(csv.DictReader(open(glob.glob(f'{d}/*kernel_trace.csv')[0])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 idx=[i for i,r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
 step=rows[idx[-2]:idx[-1]]

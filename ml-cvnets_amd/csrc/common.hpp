@@ -257,6 +257,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #define CVH_TUNE_GEMM_GRID 3     /* conv_gemm grid.x cap */
 #define CVH_TUNE_DW_XCD 4        /* depthwise: XCD-contiguous block mapping on/off */
 #define CVH_TUNE_BIG_GEMM 5    /* 1: transformer-sized linears use the 128x128 direct-to-LDS kernel (gemm_big.hip), 0: conv_gemm */
+#define CVH_TUNE_COLRED_ROWS 6 /* cap on the number of partial rows (= workgroups) of the column-reduction kernels */
 #define CVH_TUNE_MAX 16
 int cvh_tune_get(int key);
 

@@ -221,14 +221,28 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
   }
 }
 
+// sum of part[r*stride + off] over r = rl, rl+64, ... < R with 8 independent loads in flight (fp32 pairwise sum of each group of
+// 8 partial rows, fp64 across groups): the finalize kernels are latency chains, not bandwidth problems.
+__device__ __forceinline__ double strided_partial_sum(const float* __restrict__ part, int R, size_t stride, size_t off, int rl) {
+  double s = 0.0;
+  int r = rl;
+  for (; r + 7 * 64 < R; r += 8 * 64) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + j * 64) * stride + off];
+    s += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+  }
+  for (; r < R; r += 64) s += (double)part[(size_t)r * stride + off];
+  return s;
+}
+
 // sum partial rows: part[R][W] -> out[W]  (f64 accumulation); block = 64 columns x 16 row lanes
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int R, int stride, int Wd, float* __restrict__ out, float scale, int accumulate) {
   __shared__ double red[64][16];
   const int col = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
   double s = 0.0;
-  if (col < Wd)
-    for (int r = rl; r < R; r += 64) s += (double)part[(size_t)r * stride + col];
+  if (col < Wd) s = strided_partial_sum(part, R, (size_t)stride, (size_t)col, rl);
   red[rl][threadIdx.x & 15] = s;
   __syncthreads();
   if (rl == 0 && col < Wd) {
@@ -249,11 +263,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int r = rl; r < R; r += 64) {
-      a += (double)part[(size_t)r * 2 * C + c];
-      b += (double)part[(size_t)r * 2 * C + C + c];
-    }
+  if (c < C) {
+    a = strided_partial_sum(part, R, (size_t)2 * C, (size_t)c, rl);
+    b = strided_partial_sum(part, R, (size_t)2 * C, (size_t)C + c, rl);
+  }
   red[rl][0][threadIdx.x & 15] = a;
   red[rl][1][threadIdx.x & 15] = b;
   __syncthreads();
@@ -343,11 +356,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int r = rl; r < R; r += 64) {
-      a += (double)part[(size_t)r * 2 * C + c];
-      b += (double)part[(size_t)r * 2 * C + C + c];
-    }
+  if (c < C) {
+    a = strided_partial_sum(part, R, (size_t)2 * C, (size_t)c, rl);
+    b = strided_partial_sum(part, R, (size_t)2 * C, (size_t)C + c, rl);
+  }
   red[rl][0][threadIdx.x & 15] = a;
   red[rl][1][threadIdx.x & 15] = b;
   __syncthreads();
@@ -581,7 +593,7 @@ __global__ void seed_advance_kernel(unsigned long long* seed) { *seed = *seed * 
 // =============================================================================================
 // C ABI
 // =============================================================================================
-static int g_tune[CVH_TUNE_MAX] = {0, /*TN_PITCH*/ 0, /*TN_WGS*/ 512, /*GEMM_GRID*/ 512, /*DW_XCD*/ 1, /*BIG_GEMM*/ 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int g_tune[CVH_TUNE_MAX] = {0, /*TN_PITCH*/ 0, /*TN_WGS*/ 512, /*GEMM_GRID*/ 512, /*DW_XCD*/ 1, /*BIG_GEMM*/ 1, /*COLRED_ROWS*/ 2048, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 int cvh_tune_get(int key) { return (key > 0 && key < CVH_TUNE_MAX) ? g_tune[key] : 0; }
 extern "C" int cvh_set_tuning(int key, int value) {
   if (key <= 0 || key >= CVH_TUNE_MAX) return -2;
@@ -650,7 +662,8 @@ extern "C" int cvh_colreduce_rows(long long rows, int C_full) {
   const int C = col_block(C_full);
   const int RL = 256 / (C / 8);
   long long g = (rows + (long long)RL * 8 - 1) / ((long long)RL * 8);
-  if (g > 512) g = 512;
+  const int cap = g_tune[CVH_TUNE_COLRED_ROWS];
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }

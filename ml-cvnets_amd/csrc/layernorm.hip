@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 
 extern "C" int cvh_ln_bwd_rows(long long rows) {
   long long g = (rows + 15) / 16;
-  if (g > 512) g = 512;
+  const int cap = cvh_tune_get(CVH_TUNE_COLRED_ROWS);  // workgroups = partial rows of the dgamma / dbeta reduction
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }

@@ -102,6 +102,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = c_longlong if name.endswith("_elems") else c_int
+    for kv in filter(None, os.environ.get("CVH_TUNE", "").split(",")):  # developer A/B knob overrides, e.g. CVH_TUNE="6=512,2=1024"
+        k, v = kv.split("=")
+        lib.cvh_set_tuning(int(k), int(v))
     _lib = lib
     return lib
 

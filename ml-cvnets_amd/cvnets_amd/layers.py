@@ -116,7 +116,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x: Tensor) -> Tensor:
         x = ops.to_nhwc(x)
         training = self.training or not self.track_running_stats
-        if self.training and self.track_running_stats:
+        if self.training and self.track_running_stats and not ops.bn_counters_bumped():
             self.num_batches_tracked.add_(1)  # plumbing (scalar counter)
         return ops.BatchNormAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var,
                                       (ops.ACT_NONE, training, float(self.momentum), float(self.eps)))
@@ -213,7 +213,7 @@ def _conv_forward(conv: nn.Conv2d, norm: Optional[nn.Module], act: Optional[nn.M
         g, be, rm, rv = norm.weight, norm.bias, norm.running_mean, norm.running_var
         momentum, eps = norm.momentum, norm.eps
         bn_training = norm.training or not norm.track_running_stats
-        if norm.training and norm.track_running_stats:
+        if norm.training and norm.track_running_stats and not ops.bn_counters_bumped():
             norm.num_batches_tracked.add_(1)  # plumbing (scalar counter)
     if conv.groups == 1:
         return ops.conv_bn_act(x, conv.weight, conv.bias, g, be, rm, rv, stride=stride, pad=pad, dil=dil, act=a, use_bn=use_bn,

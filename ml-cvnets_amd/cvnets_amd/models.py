@@ -113,14 +113,18 @@ class MobileViT(nn.Module):
         if self.training:
             ops.advance_dropout_seed(x.device)
             ops.pack_all(self)  # every conv / linear weight packed by one launch for this step
-        x = ops.to_nhwc(x)
-        x = self.conv_1(x)
-        x = self.layer_1(x)
-        x = self.layer_2(x)
-        x = self.layer_3(x)
-        x = self.layer_4(x)
-        x = self.layer_5(x)
-        return self.conv_1x1_exp(x)
+            ops.bump_bn_counters(self)
+        try:
+            x = ops.to_nhwc(x)
+            x = self.conv_1(x)
+            x = self.layer_1(x)
+            x = self.layer_2(x)
+            x = self.layer_3(x)
+            x = self.layer_4(x)
+            x = self.layer_5(x)
+            return self.conv_1x1_exp(x)
+        finally:
+            ops.end_bn_counters()
 
     def forward_classifier(self, x: Tensor, *args, **kwargs) -> Tensor:
         x = self.extract_features(x)
@@ -317,11 +321,15 @@ class MobileViTv2(nn.Module):
         if self.training:
             ops.advance_dropout_seed(x.device)
             ops.pack_all(self)
-        x = ops.to_nhwc(x)
-        x = self.conv_1(x)
-        for idx in range(1, 6):
-            x = getattr(self, f"layer_{idx}")(x)
-        return self.conv_1x1_exp(x)
+            ops.bump_bn_counters(self)
+        try:
+            x = ops.to_nhwc(x)
+            x = self.conv_1(x)
+            for idx in range(1, 6):
+                x = getattr(self, f"layer_{idx}")(x)
+            return self.conv_1x1_exp(x)
+        finally:
+            ops.end_bn_counters()
 
     def forward_classifier(self, x: Tensor, *args, **kwargs) -> Tensor:
         return self.classifier(self.extract_features(x))

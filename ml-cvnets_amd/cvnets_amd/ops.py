@@ -244,6 +244,32 @@ def pack_all(module: torch.nn.Module, dtype: Optional[torch.dtype] = None) -> No
     plan.run()
 
 
+_COUNTERS_BUMPED = False  # True while a model forward runs whose BatchNorm step counters were advanced by one batched launch
+
+
+def bump_bn_counters(module: torch.nn.Module) -> None:
+    """num_batches_tracked += 1 for every training BatchNorm of `module` in ONE multi-tensor launch (instead of one 1-block kernel per
+    layer: 32 launches per MobileViT step); the per-layer increments are skipped until `end_bn_counters()`."""
+    global _COUNTERS_BUMPED
+    lst = module.__dict__.get("_cvh_bn_counters")
+    if lst is None:
+        lst = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        module.__dict__["_cvh_bn_counters"] = lst
+    live = [m.num_batches_tracked for m in lst if m.training and m.track_running_stats and m.num_batches_tracked is not None]
+    if live:
+        torch._foreach_add_(live, 1)
+    _COUNTERS_BUMPED = True
+
+
+def end_bn_counters() -> None:
+    global _COUNTERS_BUMPED
+    _COUNTERS_BUMPED = False
+
+
+def bn_counters_bumped() -> bool:
+    return _COUNTERS_BUMPED
+
+
 _INPLACE_PARAM_GRADS = False
 
 

@@ -155,6 +155,13 @@ def bench_all(B, reps, only):
             us = timeit(lambda: _lib.call("cvh_bn_bwd_apply", 1, x.data_ptr(), do.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), 1, st[2].data_ptr(),
                                            st[3].data_ptr(), st[4].data_ptr(), y.data_ptr(), rows_, C, s()), reps)
             add("bn_bwd_apply", name, f"rows={rows_} C={C}", us, 3 * x.numel() * ES)
+            co = torch.empty(5, C, device="cuda")
+            us = timeit(lambda: _lib.call("cvh_bn_bwd_finalize", part.data_ptr(), R, C, float(rows_), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
+                                           1, 0, co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), co[4].data_ptr(), s()), reps)
+            add("bn_bwd_finalize", name, f"C={C}", us, R * 2 * C * 4)
+            us = timeit(lambda: _lib.call("cvh_bn_finalize", part.data_ptr(), R, C, float(rows_), st[0].data_ptr(), st[1].data_ptr(), st[5].data_ptr(),
+                                           st[6].data_ptr(), 0.1, 1e-5, co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), s()), reps)
+            add("bn_finalize", name, f"C={C}", us, R * 2 * C * 4)
     return rows
 
 

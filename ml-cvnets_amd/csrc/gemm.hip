@@ -296,19 +296,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 // Both operand tiles are transposed on their way into LDS (so fragments are contiguous in m):
 // lanes run along m in row PAIRS and write packed {row 2i, row 2i+1} words.
 // =============================================================================================
-struct GemmTNParams {
-  const void* dy;
-  const void* src1;
-  const void* src2;
-  int C1, C2;
-  float* dw;
-  int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
-  int M, N, Ktot;
-  int Cin_real;
-  int m_per_split;
-  int k_tiles;
-  float* part;  // [splits][N][Ktot] partial products (no atomics); nullptr -> fp32 atomics straight into dw
-};
 
 __device__ __forceinline__ void store_transposed_pair(bf16_t* dst, int pitch, const V8<bf16_t>& r0, const V8<bf16_t>& r1) {
   const uint32_t a[4] = {r0.d.x, r0.d.y, r0.d.z, r0.d.w};
@@ -612,21 +599,61 @@ extern "C" int cvh_conv_dx_patch(int dtype, const void* dy, const void* wgt, voi
   return -1;
 }
 
+static bool tn_big_shape(int M, int N, int Ktot) { return M >= 2048 && N >= 256 && (N % 128) == 0 && Ktot >= 256 && (Ktot % 128) == 0; }
+
 static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* splits, int* mps) {
   const int n_tiles = (N + 127) / 128;
   *k_tiles = (Ktot + 127) / 128;
   *out_tiles = n_tiles * *k_tiles;
-  // enough splits over M to put ~2 deep-prefetching workgroups on every CU
-  // (K-heavy 3x3 problems have many output tiles and long per-split MFMA chains: they like twice as many workgroups)
-  const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS) * (*out_tiles >= 8 ? 2 : 1);
-  int sp = (target_wgs + *out_tiles - 1) / *out_tiles;
+  int sp;
+  if (tn_big_shape(M, N, Ktot)) {
+    // transformer-sized dW (gemm_tn128_kernel, 2 workgroups per CU = 512 slots): pick the split count that minimises
+    // (rounds of workgroups) x (64-row steps per split) + the cost of summing the partial tiles.  Plain "enough workgroups"
+    // planning lands on e.g. 144 tiles x 8 splits = 2.25 rounds, i.e. a third of the machine idle in the last round.
+    const int slots = 512, total_steps = (M + 63) / 64;
+    double best = 1e30;
+    sp = 1;
+    for (int s = 1; s <= 32 && s <= total_steps; ++s) {
+      const int rounds = (*out_tiles * s + slots - 1) / slots;
+      const int steps = (total_steps + s - 1) / s;
+      const double t = (double)rounds * steps * 1.8 + (double)(s + 1) * (double)N * Ktot * 4.0 / 3.0e6;  // microseconds
+      if (t < best) { best = t; sp = s; }
+    }
+  } else {
+    // enough splits over M to put ~2 deep-prefetching workgroups on every CU
+    // (K-heavy 3x3 problems have many output tiles and long per-split MFMA chains: they like twice as many workgroups)
+    const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS) * (*out_tiles >= 8 ? 2 : 1);
+    sp = (target_wgs + *out_tiles - 1) / *out_tiles;
+  }
   int max_splits = (M + 255) / 256;
   if (sp > max_splits) sp = max_splits;
   if (sp < 1) sp = 1;
   int m = (M + sp - 1) / sp;
-  m = ((m + 31) / 32) * 32;
+  m = ((m + 63) / 64) * 64;  // whole 64-row reduction steps (gemm_tn128_kernel); also a multiple of the 32-row step of gemm_tn_kernel
   *splits = (M + m - 1) / m;
   *mps = m;
+}
+
+// part[split][total] -> dw[total] (linear layers: torch layout == GEMM layout), 16 bytes per lane, splits summed in registers
+__global__ __launch_bounds__(256) void gemm_dw_reduce_linear_kernel(const float* __restrict__ part, int splits, size_t total4, float* __restrict__ dw,
+                                                                    int accumulate) {
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(part);
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(dw);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    float4 s = accumulate ? d4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = 0;
+    for (; sp + 3 < splits; sp += 4) {  // four independent loads in flight
+      const float4 a = p4[(size_t)sp * total4 + i], b = p4[(size_t)(sp + 1) * total4 + i];
+      const float4 c = p4[(size_t)(sp + 2) * total4 + i], d = p4[(size_t)(sp + 3) * total4 + i];
+      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+      s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; sp < splits; ++sp) {
+      const float4 a = p4[(size_t)sp * total4 + i];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    d4[i] = s;
+  }
 }
 
 extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
@@ -659,13 +686,22 @@ extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const vo
   }
   dim3 grid(out_tiles, splits);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == CVH_DT_BF16) {
+  if (dtype == CVH_DT_BF16 && p.part != nullptr && gemm_tn_big_eligible(p)) {  // transformer-sized linears (ViT-B / CLIP)
+    const int rc = launch_gemm_tn_big(p, splits, st);
+    if (rc) return rc;
+  } else if (dtype == CVH_DT_BF16) {
     if (cvh_tune_get(CVH_TUNE_TN_PITCH)) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0>), grid, dim3(256), 0, st, p);
   } else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0>), grid, dim3(256), 0, st, p);
   else return -1;
   CVH_CHECK_LAUNCH();
-  if (p.part) {
+  if (p.part && KH * KW == 1 && Cin_real == p.Ktot && ((size_t)N * p.Ktot) % 4 == 0 && splits <= 64 && (size_t)N * p.Ktot >= 65536) {
+    const size_t total4 = (size_t)N * p.Ktot / 4;
+    int g = (int)((total4 + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(gemm_dw_reduce_linear_kernel, dim3(g), dim3(256), 0, st, p.part, splits, total4, dw, accumulate);
+    CVH_CHECK_LAUNCH();
+  } else if (p.part) {
     const size_t total = (size_t)N * p.Ktot;
     int g = (int)((total + 15) / 16);
     if (g > 4096) g = 4096;

@@ -166,3 +166,121 @@ int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
   CVH_CHECK_LAUNCH();
   return 0;
 }
+
+// =============================================================================================
+// dW of a transformer-sized linear layer:  part[split][n][k] = sum_{m in split} dY[m][n] * X[m][k]       (bf16, fp32 partials)
+// Both operands are M-major in HBM while the MFMA wants 8 consecutive reduction (m) elements per lane.  Instead of transposing on
+// the way into LDS (gemm_tn_kernel's register path) the tiles go HBM/L2 -> LDS untouched with global_load_lds and the fragments are
+// gathered by the gfx950 LDS transpose read (ds_read_b64_tr_b16: a 16-lane group reads a [4 m][16 col] block and every lane
+// receives 4 consecutive m of ONE column; two reads = one 32x32x16 operand).
+//   * tile 128 (n) x 128 (k) per workgroup, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 accumulators; reduction step 64 rows of m;
+//   * LDS image per operand and step: 16 sub-tiles [16 m][32 col] (64-byte rows, 1 KB = one wave-wide direct-to-LDS write with
+//     lane -> (row lane>>2, 16-byte chunk lane&3)); the 4 rows x 32 bytes a 16-lane group reads are 64 bytes apart -> 32 distinct
+//     banks, the two groups of a 32-lane half take the other 32: conflict-free;
+//   * rows past the end of the split read a zero line, so any M works; splits over M fill the chip, gemm_dw_reduce_kernel sums them.
+// =============================================================================================
+namespace {
+__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];  // zero-initialised: source of out-of-range rows
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+typedef short tr_v8s __attribute__((ext_vector_type(8)));
+
+// operand fragment for columns [col0, col0+32) and reduction rows [16*kk, 16*kk+16) of a [64 m][128 col] sub-tiled LDS image
+__device__ __forceinline__ Frag<bf16_t> frag_tr(const unsigned char* img, int kk, int col0, int lane) {
+  const int i = lane & 15;
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  const int r = 8 * (lane >> 5) + (i >> 2);
+  const unsigned char* p = img + (kk * 4 + (col >> 5)) * 1024 + r * 64 + (col & 31) * 2;
+  const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
+  const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + 4 * 64));
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  return f;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (dY image 16 KB | X image 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 1, wave_k = wave & 1;
+  const int n0 = (blockIdx.x / p.k_tiles) * 128, k0 = (blockIdx.x % p.k_tiles) * 128;
+  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(p.dy);
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.src1);
+  const int N = p.N, K = p.Ktot;
+
+  // direct-to-LDS assignment: wave w owns tile rows [16w, 16w+16) of every step; instruction j covers columns [32j, 32j+32)
+  const int row_off = 16 * wave + (lane >> 2);
+  const bf16_t* gy = dy + (size_t)(m_begin + row_off) * N + n0 + (lane & 3) * 8;
+  const bf16_t* gx = x + (size_t)(m_begin + row_off) * K + k0 + (lane & 3) * 8;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_line);
+  auto issue = [&](int step, int buf) {
+    const bool ok = m_begin + step * 64 + row_off < m_end;
+    unsigned char* y_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024;
+    unsigned char* x_dst = y_dst + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(ok ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
+      glds16(ok ? gx + (size_t)step * 64 * K + j * 32 : zero, x_dst + j * 1024);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
+
+  const int steps = (m_end - m_begin + 63) / 64;
+  if (steps > 0) {
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < steps) issue(st + 1, buf ^ 1);
+    const unsigned char* Yt = smem + buf * BUF_BYTES;
+    const unsigned char* Xt = Yt + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      Frag<bf16_t> a0 = frag_tr(Yt, kk, wave_n * 64, lane);
+      Frag<bf16_t> a1 = frag_tr(Yt, kk, wave_n * 64 + 32, lane);
+      Frag<bf16_t> b0 = frag_tr(Xt, kk, wave_k * 64, lane);
+      Frag<bf16_t> b1 = frag_tr(Xt, kk, wave_k * 64 + 32, lane);
+      mma32(acc[0][0], a0, b0);
+      mma32(acc[0][1], a0, b1);
+      mma32(acc[1][0], a1, b0);
+      mma32(acc[1][1], a1, b1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  float* dst0 = p.part + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+    for (int fk = 0; fk < 2; ++fk) {
+      const int k = k0 + wave_k * 64 + fk * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
+        dst0[(size_t)n * K + k] = acc[fn][fk][r];
+      }
+    }
+}
+
+bool gemm_tn_big_eligible(const GemmTNParams& p) {
+  if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
+  const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
+  return linear && p.M >= 2048 && p.N >= 256 && (p.N % 128) == 0 && p.Ktot >= 256 && (p.Ktot % 128) == 0 && p.Cin_real == p.Ktot &&
+         (p.m_per_split % 64) == 0;
+}
+
+int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st) {
+  const int out_tiles = (p.N / 128) * (p.Ktot / 128);
+  hipLaunchKernelGGL(gemm_tn128_kernel, dim3(out_tiles, splits), dim3(256), 2 * BUF_BYTES, st, p);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

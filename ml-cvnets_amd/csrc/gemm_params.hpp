@@ -26,6 +26,22 @@ struct ConvGemmParams {
   int sc_s, sc_KW, sc_C, sc_H, sc_W, sc_Ho, sc_Wo;
 };
 
+struct GemmTNParams {
+  const void* dy;
+  const void* src1;
+  const void* src2;
+  int C1, C2;
+  float* dw;
+  int B, H, W, Ho, Wo, KH, KW, stride, pad, dil;
+  int M, N, Ktot;
+  int Cin_real;
+  int m_per_split;
+  int k_tiles;
+  float* part;  // [splits][N][Ktot] partial products (no atomics); nullptr -> fp32 atomics straight into dw
+};
+
 // gemm_big.hip
+bool gemm_tn_big_eligible(const GemmTNParams& p);
+int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st);
 bool gemm_big_eligible(const ConvGemmParams& p);
 int launch_gemm_big(const ConvGemmParams& p, hipStream_t st);

@@ -367,6 +367,41 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restric
   }
 }
 
+// c % 4 == 0: lanes run ALONG the row (8-byte chunks of 4 channels, so a wave reads 512 contiguous bytes instead of 64 separate
+// cache lines) and the per-head sums are formed with LDS float atomics.  Block = 8 tokens x all d/4 chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_prep_rows_kernel(const T* __restrict__ o, const T* __restrict__ dout, AttnParams p) {
+  constexpr int TB = 8;
+  __shared__ float acc[TB * 64];  // [token][head], h <= 64
+  __shared__ int rows[TB];
+  const int cpr = p.d / 4;  // chunks per row
+  const size_t ntok = (size_t)p.nseq * p.S;
+  for (size_t t0 = (size_t)blockIdx.x * TB; t0 < ntok; t0 += (size_t)gridDim.x * TB) {
+    for (int i = threadIdx.x; i < TB * p.h; i += 256) acc[i] = 0.f;
+    if (threadIdx.x < TB) {
+      const size_t t = t0 + threadIdx.x;
+      rows[threadIdx.x] = t < ntok ? seq_row(p.map, (int)(t / p.S), (int)(t % p.S)) : -1;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TB * cpr; idx += 256) {
+      const int tl = idx / cpr, ch = idx - tl * cpr;
+      const int row = rows[tl];
+      if (row < 0) continue;
+      float a[4], b[4];
+      v4_unpack(v4_load<T>(o + (size_t)row * p.d + ch * 4), a);
+      v4_unpack(v4_load<T>(dout + (size_t)row * p.d + ch * 4), b);
+      atomicAdd(&acc[tl * p.h + (ch * 4) / p.c], (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TB * p.h; i += 256) {
+      const int tl = i / p.h, head = i - tl * p.h;
+      const size_t t = t0 + tl;
+      if (t < ntok) p.dsum[((size_t)(t / p.S) * p.h + head) * p.S + (t % p.S)] = acc[i];
+    }
+    __syncthreads();
+  }
+}
+
 // =============================================================================================
 // backward dQ: wave = (sequence, head, 32-query block); the NW waves of a workgroup share the K/V tiles
 // =============================================================================================
@@ -722,11 +757,20 @@ extern "C" int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const v
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
     const int vec = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
+    if (vec == 4 && h <= 64) {
+      const size_t ntok = (size_t)nseq * S;
+      int gr = (int)((ntok + 7) / 8);
+      if (gr > 8192) gr = 8192;
+      if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((attn_bwd_prep_rows_kernel<bf16_t>), dim3(gr), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, p);
+      else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((attn_bwd_prep_rows_kernel<float>), dim3(gr), dim3(256), 0, st, (const float*)out, (const float*)dout, p);
+      else return -1;
+    } else {
 #define PREP(TT, VV) hipLaunchKernelGGL((attn_bwd_prep_kernel<TT, VV>), dim3(g), dim3(256), 0, st, (const TT*)out, (const TT*)dout, p)
     if (dtype == CVH_DT_BF16) { if (vec == 4) PREP(bf16_t, 4); else if (vec == 2) PREP(bf16_t, 2); else PREP(bf16_t, 1); }
     else if (dtype == CVH_DT_F32) { if (vec == 4) PREP(float, 4); else if (vec == 2) PREP(float, 2); else PREP(float, 1); }
     else return -1;
 #undef PREP
+    }
     CVH_CHECK_LAUNCH();
   }
   int rc = dispatch_attn(dtype, K_DQ, p, st);

@@ -13,6 +13,8 @@ Tensor conventions
 """
 from __future__ import annotations
 
+import os
+
 import itertools
 import weakref
 from typing import Optional, Tuple
@@ -342,18 +344,72 @@ def _act_backward(pre: torch.Tensor, dout: torch.Tensor, act: int, rows: int, C:
 def _colsum(x2d: torch.Tensor, rows: int, C: int, sink: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """column sums (bias gradients); with a sink the result is added into it and None is returned"""
     R = _lib.query("cvh_colreduce_rows", rows, C)
+    side = _param_grad_stream(x2d.device) if sink is not None else None
+    if side is not None:
+        with torch.cuda.stream(side):
+            part = _f32(R * 2 * C, x2d.device)
+            x2d.record_stream(side)
+            _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), _p(sink), 1.0, 1, _stream())
+        return None
     part = _f32(R * 2 * C, x2d.device)
     out = sink if sink is not None else _f32(C, x2d.device)
     _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), _p(out), 1.0, 1 if sink is not None else 0, _stream())
     return None if sink is not None else out
 
 
+# ------------------------------------------------------------------------------------------------
+# parameter-gradient side stream
+# ------------------------------------------------------------------------------------------------
+# dW (and bias-gradient) kernels are off the backward critical path: nothing in the backward pass reads them, only the optimizer
+# does.  With in-place parameter gradients they are launched on a SIDE HIP stream behind an event on the main stream, so the many
+# under-filled dW / reduce launches of the small layers overlap with the dX chain; the main stream re-joins at the end of the
+# backward pass (autograd end-of-backward callback).  Captured into a hipGraph this becomes two parallel branches per layer.
+_ASYNC_PARAM_GRADS = os.environ.get("CVH_ASYNC_DW", "1") != "0"
+_side_streams = {}
+_side_join_queued = False
+
+
+def _param_grad_stream(device):
+    """returns the side stream (already made to wait for everything queued so far on the current stream) or None"""
+    global _side_join_queued
+    if not (_ASYNC_PARAM_GRADS and _INPLACE_PARAM_GRADS):
+        return None
+    side = _side_streams.get(device)
+    if side is None:
+        side = _side_streams[device] = torch.cuda.Stream(device=device)
+    if not _side_join_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_param_grad_stream)
+        except RuntimeError:  # not inside a backward pass (direct Function.backward call in a test)
+            return None
+        _side_join_queued = True
+    side.wait_stream(torch.cuda.current_stream(device))
+    return side
+
+
+def _join_param_grad_stream():
+    global _side_join_queued
+    _side_join_queued = False
+    for dev, side in _side_streams.items():
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+
 def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real):
     """dW = dY^T x im2col(x): split over M into a scratch buffer + one reduce kernel (no atomics, no zero-fill).  Returns the
     gradient tensor, or None when it was added in place into weight.grad."""
     sink = _grad_sink(weight)
-    dw = sink if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
     n_scr = _lib.query("cvh_gemm_dw_scratch_elems", B * Ho * Wo, N, KH * KW * (C1 + C2))
+    side = _param_grad_stream(dy.device) if sink is not None else None
+    if side is not None:
+        with torch.cuda.stream(side):
+            scr = _f32(max(n_scr, 1), dy.device)
+            for t in (dy, x, x2):
+                if t is not None:
+                    t.record_stream(side)
+            _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(sink), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real,
+                      _p(scr), n_scr, 1, _stream())
+        return None
+    dw = sink if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
     scr = _f32(max(n_scr, 1), dy.device)
     _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real,
               _p(scr), n_scr, 1 if sink is not None else 0, _stream())

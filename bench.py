@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="torch.optim.AdamW(fused=True) instead of the one-launch cvh_adamw_multi step")
+    ap.add_argument("--torch-loss", action="store_true", help="F.cross_entropy instead of the cvh_ce_* kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -125,7 +127,10 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = None
     if not args.no_optimizer:
-        opt = torch.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01, fused=True, capturable=True)
+        if args.torch_optimizer:
+            opt = torch.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01, fused=True, capturable=True)
+        else:  # every parameter stepped by one kernel launch, rates and step counter on the device
+            opt = cvnets_amd.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01)
 
     x = torch.randn(args.batch, 3, args.res, args.res, device=dev)
     y = torch.randint(0, 1000, (args.batch,), device=dev)
@@ -135,7 +140,10 @@ def main():
 
     def fwd_bwd():
         logits = model(x)
-        loss = F.cross_entropy(logits.float(), y, label_smoothing=0.1)
+        if args.torch_loss:
+            loss = F.cross_entropy(logits.float(), y, label_smoothing=0.1)
+        else:  # loss_fn/classification/cross_entropy.py:65-92 in one HIP kernel per direction
+            loss = cvnets_amd.ops.cross_entropy(logits, y, 0.1)
         loss.backward()
         return loss
 
@@ -155,7 +163,7 @@ def main():
             if world > 1:
                 ddp.allreduce_flat()
         if opt is not None and (graph is None or world > 1):
-            opt.step()
+            opt_step()
 
     # eager warm-up (also creates every lazily-built tensor before capture)
     side = torch.cuda.Stream()
@@ -167,17 +175,24 @@ def main():
             if opt is not None:
                 opt.step()
     torch.cuda.current_stream().wait_stream(side)
+
+    def opt_step():
+        if args.torch_optimizer:
+            opt.step()
+        else:
+            opt.step(sync_hyperparameters=False)  # constant rate in this benchmark: the device-side table was filled by the warm-up steps
     torch.cuda.synchronize()
 
     graph_err = None
     if use_graph:
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 ddp.zero_grad()
                 static_loss = fwd_bwd()
                 if opt is not None and world == 1:
-                    opt.step()
+                    opt_step()
             graph = g
         except Exception as e:  # pragma: no cover - reported in the JSON line
             graph_err = f"{type(e).__name__}: {e}"[:300]
@@ -247,7 +262,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic (randn images, random-init weights)",
             "config": {"workload": f"MobileViT-{args.mode} {args.res}x{args.res}, {args.batch} img/GPU, global batch {args.batch * world}",
-                       "step": "zero_grad+fwd+CE(ls=0.1)+bwd" + ("+allreduce" if world > 1 else "") + ("" if opt is None else "+AdamW"),
+                       "step": "zero_grad+fwd+CE(ls=0.1)+bwd" + ("+allreduce" if world > 1 else "") + ("" if opt is None else ("+AdamW(torch fused)" if args.torch_optimizer else "+AdamW(cvh_adamw_multi)")),
                        "parallelism": f"dp{world}", "hipgraph": graph is not None, "dropout": 0.1, "loss": round(loss_val, 4)},
             "images_per_sec_per_gpu": round(per_gpu, 2),
             "roofline": roofline,

@@ -139,6 +139,26 @@ int cvh_scaled_ce_fwd(int dtype, const void* logits, const float* scale, float* 
 int cvh_scaled_ce_bwd(int dtype, const void* logits, const float* scale, const float* lse, const float* gout, void* dlogits,
                       float* dscale_rows, int N, int M, int label_offset, void* stream);
 
+/* ---- optimizer + EMA step (SURVEY 8f "next" row 1) ------------------------------------------------- */
+/* torch.optim.AdamW as configured by optim/adamw.py:16-46 (decoupled weight decay, bias correction, no amsgrad) for ALL parameter
+ * tensors in one launch, optionally followed in the same pass by EMA.update_parameters (cvnets/misc/averaging_utils.py:43-55).
+ * table[n+1][8] int64 = {param ptr, grad ptr, ema ptr or 0, offset into the flat moment buffers, numel, group index, prefix start, 0};
+ * group_hp[g][2] = {lr, weight_decay} and *step (number of steps taken so far, advanced by the call) live on the device so the
+ * launch is hipGraph-capturable; inv_grad_scale (nullable) multiplies the gradients (GradScaler unscale). */
+int cvh_adamw_multi(const long long* table, int n_tensors, long long total, float* m_flat, float* v_flat, const float* group_hp, float beta1,
+                    float beta2, float eps, float* step, const float* inv_grad_scale, float ema_momentum, void* stream);
+/* dst = dst*(1-momentum) + momentum*src over a table[n+1][4] = {dst ptr, src ptr, numel, prefix start}: EMA of the float buffers */
+int cvh_lerp_multi(const long long* table, int n_tensors, long long total, float momentum, void* stream);
+
+/* ---- classification loss (SURVEY 8f "next" row 2) -------------------------------------------------- */
+/* CrossEntropy._compute_loss (loss_fn/classification/cross_entropy.py:65-92) = F.cross_entropy(logits[N][M], labels, weight=None,
+ * ignore_index, label_smoothing), per-row part: loss_rows[N] (0 for ignored rows) and lse[N]; the mean over valid rows is the
+ * caller's.  bwd: dlogits = *gout * (softmax - (1-eps) * onehot - eps/M), *gout = upstream gradient / number of valid rows. */
+int cvh_ce_fwd(int dtype, const void* logits, const long long* labels, float label_smoothing, long long ignore_index, float* loss_rows,
+               float* lse, int N, int M, void* stream);
+int cvh_ce_bwd(int dtype, const void* logits, const long long* labels, const float* lse, const float* gout, float label_smoothing,
+               long long ignore_index, void* dlogits, int N, int M, void* stream);
+
 /* ---- MobileViTv2: GroupNorm(1) ("layer_norm_2d") and linear self-attention ------------------------------ */
 /* LayerNorm2D_NCHW = nn.GroupNorm(num_groups=1) (cvnets/layers/normalization/layer_norm.py:75-108) on an NHWC map [B][HW][C]:
  * per-sample statistics over HW*C, per-channel affine.  stats[B][2] = (mean, rstd) is written by fwd and read by bwd;

@@ -239,6 +239,52 @@ __global__ void __launch_bounds__(256) scaled_ce_bwd_kernel(const T* __restrict_
   if (threadIdx.x == 0) dscale_rows[i] = g * (scr[0] + scr[1] + scr[2] + scr[3]);
 }
 
+// Label-smoothed cross-entropy over [N][M] logits (loss_fn/classification/cross_entropy.py:65-92 -> F.cross_entropy(weight=None,
+// ignore_index, label_smoothing)): loss_i = lse_i - (1-eps)*z[y_i] - eps*mean_j z_ij ; rows with y_i == ignore_index give 0.
+// One 256-thread block per row; fp32 math whatever the logits dtype.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const long long* __restrict__ labels, float eps, long long ignore_index,
+                                                     float* __restrict__ loss_rows, float* __restrict__ lse, int N, int M) {
+  __shared__ float scr[12];
+  const int i = blockIdx.x;
+  const T* row = logits + (size_t)i * M;
+  float mx = -INFINITY, sm = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const float z = to_f<T>(row[j]);
+    mx = fmaxf(mx, z);
+    sm += z;
+  }
+  mx = wave_max(mx);
+  sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) { scr[threadIdx.x >> 6] = mx; scr[4 + (threadIdx.x >> 6)] = sm; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
+  sm = (scr[4] + scr[5]) + (scr[6] + scr[7]);
+  float ex = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) ex += __expf(to_f<T>(row[j]) - mx);
+  ex = wave_sum(ex);
+  if ((threadIdx.x & 63) == 0) scr[8 + (threadIdx.x >> 6)] = ex;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l = mx + __logf((scr[8] + scr[9]) + (scr[10] + scr[11]));
+    lse[i] = l;
+    const long long y = labels[i];
+    loss_rows[i] = (y == ignore_index) ? 0.f : l - (1.f - eps) * to_f<T>(row[y]) - eps * sm / (float)M;
+  }
+}
+// dlogits[i][j] = g * (softmax_ij - (1-eps)*[j == y_i] - eps/M),  g = *gout (upstream gradient / number of valid rows); 0 for ignored rows
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, const long long* __restrict__ labels, const float* __restrict__ lse,
+                                                     const float* __restrict__ gout, float eps, long long ignore_index, T* __restrict__ dlogits, int N, int M) {
+  const int i = blockIdx.x;
+  const long long y = labels[i];
+  const float l = lse[i], g = (y == ignore_index) ? 0.f : *gout, u = eps / (float)M;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const float p = __expf(to_f<T>(logits[(size_t)i * M + j]) - l);
+    dlogits[(size_t)i * M + j] = from_f<T>(g * (p - (j == y ? 1.f - eps : 0.f) - u));
+  }
+}
+
 static inline int tk_grid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
@@ -324,6 +370,20 @@ extern "C" int cvh_scaled_ce_bwd(int dtype, const void* logits, const float* sca
                                  float* dscale_rows, int N, int M, int label_offset, void* stream) {
   if (N <= 0 || M <= 0 || label_offset < 0 || N + label_offset > M) return -2;
   TK_DISPATCH(dtype, hipLaunchKernelGGL((scaled_ce_bwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, scale, lse, gout, (T*)dlogits, dscale_rows, N, M, label_offset);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_ce_fwd(int dtype, const void* logits, const long long* labels, float label_smoothing, long long ignore_index, float* loss_rows,
+                          float* lse, int N, int M, void* stream) {
+  if (N <= 0 || M <= 0) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((ce_fwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, labels, label_smoothing, ignore_index, loss_rows, lse, N, M);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_ce_bwd(int dtype, const void* logits, const long long* labels, const float* lse, const float* gout, float label_smoothing,
+                          long long ignore_index, void* dlogits, int N, int M, void* stream) {
+  if (N <= 0 || M <= 0) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, labels, lse, gout, label_smoothing, ignore_index, (T*)dlogits, N, M);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -58,6 +58,10 @@ SIGNATURES = {
     "cvh_l2norm_bwd": [I, P, P, P, P, I, I, F, P],
     "cvh_scaled_ce_fwd": [I, P, P, P, P, I, I, I, P],
     "cvh_scaled_ce_bwd": [I, P, P, P, P, P, P, I, I, I, P],
+    "cvh_adamw_multi": [P, I, L, P, P, P, F, F, F, P, P, F, P],
+    "cvh_lerp_multi": [P, I, L, F, P],
+    "cvh_ce_fwd": [I, P, P, F, L, P, P, I, I, P],
+    "cvh_ce_bwd": [I, P, P, P, P, F, L, P, I, I, P],
     "cvh_gn_chunks": [I, I, I],
     "cvh_gn_fwd": [I, P, P, P, P, P, P, I, I, I, F, P],
     "cvh_gn_bwd": [I, P, P, P, P, P, P, P, I, I, I, P],

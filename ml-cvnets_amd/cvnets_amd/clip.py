@@ -2,7 +2,7 @@
 ``SimpleImageProjectionHead`` (cvnets/image_projection_layers/simple_projection_head.py:17-85), ``CLIP``
 (cvnets/models/multi_modal_img_text/clip.py:24-228) and ``ContrastiveLossClip``
 (loss_fn/multi_modal_img_text/contrastive_loss_clip.py:20-172) — same constructor signatures, attribute trees and state_dict keys;
-forward/backward run the HIP kernels (token embedding, causal fused attention, GEMMs, LayerNorm, EOT gather, L2 normalise, scaled CE).
+forward/backward run the HIP kernels (token embedding, causal fused attention, GEMMs, LayerNorm, EOT gather, L2 normalise); the losses live in losses.py.
 """
 from __future__ import annotations
 
@@ -184,42 +184,6 @@ class CLIP(nn.Module):
         text_encoder = TextTransformer(opts, projection_dim=projection_dim)
         image_encoder.classifier = SimpleImageProjectionHead(opts, in_dim=image_encoder.classifier.in_features, out_dim=projection_dim)
         return cls(opts, image_encoder=image_encoder, text_encoder=text_encoder)
-
-
-class ContrastiveLossClip(nn.Module):
-    """loss_fn/multi_modal_img_text/contrastive_loss_clip.py:20-142.  The two [N, N*W] logit GEMMs run on the MFMA linear kernel,
-    the scaled cross-entropies in cvh_scaled_ce_*; cross-rank features come from an autograd-aware RCCL all-gather (ddp.py)."""
-
-    def __init__(self, opts, *args, **kwargs) -> None:
-        super().__init__()
-        self.rank = opt(opts, "ddp.rank", 0)
-        self.use_distributed = opt(opts, "ddp.use_distributed", False)
-
-    def _forward_clip(self, prediction: Dict[str, Tensor], *args, **kwargs) -> Dict[str, Tensor]:
-        from .ddp import gather_all_features
-
-        if not {"image", "text"}.issubset(prediction.keys()):
-            raise KeyError(f"image and text are mandatory keys for {self.__class__.__name__}.")
-        image_features, text_features = prediction.pop("image"), prediction.pop("text")
-        logit_scale = prediction.pop("logit_scale", 1.0)
-        if image_features is None or text_features is None:
-            raise ValueError(f"Image / text features can't be None in {self.__class__.__name__}")
-        if not isinstance(logit_scale, Tensor):
-            logit_scale = torch.tensor(float(logit_scale), device=image_features.device)
-        g_img, g_txt = image_features, text_features
-        if self.use_distributed:
-            g_img, g_txt = gather_all_features(image_features), gather_all_features(text_features)
-        logits_per_image = ops.linear(image_features.contiguous(), g_txt)  # image @ gathered_text^T  (scale applied inside the CE kernel)
-        logits_per_text = ops.linear(text_features.contiguous(), g_img)
-        offset = image_features.shape[0] * self.rank
-        text_loss = ops.scaled_cross_entropy(logits_per_text, logit_scale, offset) * 0.5
-        image_loss = ops.scaled_cross_entropy(logits_per_image, logit_scale, offset) * 0.5
-        return {"total_loss": image_loss + text_loss, "image_loss": image_loss, "text_loss": text_loss, "logit_scale": logit_scale}
-
-    def forward(self, input_sample, prediction: Dict[str, Tensor], *args, **kwargs) -> Dict:
-        if not self.training:
-            return {"total_loss": torch.tensor(0.0, device=prediction["logit_scale"].device)}
-        return self._forward_clip(prediction=prediction)
 
 
 def build_clip(opts=None, **overrides) -> CLIP:

@@ -1090,6 +1090,38 @@ class ScaledCrossEntropy(torch.autograd.Function):
         return dlogits, ds_rows.sum().reshape(()), None
 
 
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits [N, M], labels [N], ignore_index, label_smoothing), mean over the non-ignored rows
+    (loss_fn/classification/cross_entropy.py:65-92)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, label_smoothing, ignore_index):
+        _check_dev(logits)
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        N, M = logits.shape
+        rows, lse = _f32(N, logits.device), _f32(N, logits.device)
+        _lib.call("cvh_ce_fwd", _dt(logits), _p(logits), _p(labels), float(label_smoothing), int(ignore_index), _p(rows), _p(lse), N, M, _stream())
+        n_valid = (labels != ignore_index).sum().clamp_(min=1).float()  # plumbing: label bookkeeping
+        ctx.save_for_backward(logits, labels, lse, n_valid)
+        ctx.cfg = (float(label_smoothing), int(ignore_index))
+        return rows.sum() / n_valid  # plumbing: N-element reduction
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse, n_valid = ctx.saved_tensors
+        eps, ignore = ctx.cfg
+        N, M = logits.shape
+        gout = (g.float() / n_valid).reshape(1)  # plumbing: scalar
+        dlogits = torch.empty_like(logits)
+        _lib.call("cvh_ce_bwd", _dt(logits), _p(logits), _p(labels), _p(lse), _p(gout), eps, ignore, _p(dlogits), N, M, _stream())
+        return dlogits, None, None, None
+
+
+def cross_entropy(logits, labels, label_smoothing: float = 0.0, ignore_index: int = -1):
+    return CrossEntropyFn.apply(logits, labels, float(label_smoothing), int(ignore_index))
+
+
 def scaled_cross_entropy(logits, scale, label_offset: int = 0):
     return ScaledCrossEntropy.apply(logits, scale, int(label_offset))
 

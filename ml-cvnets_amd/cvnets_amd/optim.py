@@ -1,0 +1,122 @@
+"""Fused optimizer / EMA step (SURVEY §8f "next" row 1): ``AdamW`` with torch.optim.AdamW's interface (param_groups, state_dict-free
+stepping, per-group ``lr`` / ``weight_decay`` that a scheduler may rewrite every iteration — optim/adamw.py:16-46,
+optim/scheduler/*) whose ``step()`` is ONE kernel launch over every parameter tensor (cvh_adamw_multi), optionally folding
+``EMA.update_parameters`` (cvnets/misc/averaging_utils.py:43-55) into the same pass."""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 amsgrad: bool = False, ema: Optional[tuple] = None, ema_momentum: float = 0.0005):
+        """ema = (model, ema_model): ema_model (a deepcopy of model, averaging_utils.py:33) is updated in the same pass"""
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not on the HIP hot path")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        b = {tuple(g["betas"]) for g in self.param_groups} | {(g["eps"],) for g in self.param_groups}
+        if len(b) != 2:
+            raise NotImplementedError("per-group betas / eps are not supported (the reference uses one setting, optim/adamw.py:30-40)")
+        self._plan = None
+        self._ema = ema
+        self.ema_momentum = float(ema_momentum)
+
+    # -------------------------------------------------------------------------------------------------
+    def _build(self):
+        entries = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if p.requires_grad:
+                    entries.append((p, gi))
+        if not entries:
+            raise RuntimeError("no trainable parameters")
+        dev = entries[0][0].device
+        if dev.type != "cuda":
+            raise RuntimeError("cvnets_amd.optim.AdamW has no CPU path")
+        ema_by_id = {}
+        if self._ema is not None:  # pair parameters by registration order (EMA model = deepcopy of the model)
+            model, ema_model = self._ema
+            for p, e in zip(model.parameters(), ema_model.parameters()):
+                if p.shape != e.shape:
+                    raise RuntimeError("EMA model does not mirror the model")
+                ema_by_id[id(p)] = e
+        rows, off = [], 0
+        for p, gi in entries:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("parameters must be contiguous float32")
+            if p.grad is None:  # plumbing: the kernel reads every gradient, absent ones count as zero
+                p.grad = torch.zeros_like(p)
+            e = ema_by_id.get(id(p))
+            rows.append([p.data_ptr(), p.grad.data_ptr(), e.data_ptr() if e is not None else 0, off, p.numel(), gi, off, 0])
+            off += p.numel()
+        rows.append([0, 0, 0, 0, 0, 0, off, 0])
+        plan = {
+            "entries": entries, "total": off, "n": len(entries), "device": dev,
+            "table": torch.tensor(rows, dtype=torch.int64, device=dev),
+            "m": torch.zeros(off, dtype=torch.float32, device=dev), "v": torch.zeros(off, dtype=torch.float32, device=dev),
+            "step": torch.zeros(1, dtype=torch.float32, device=dev),
+            "hp": torch.zeros(len(self.param_groups), 2, dtype=torch.float32, device=dev),
+            "hp_host": None, "grad_ptrs": [p.grad.data_ptr() for p, _ in entries],
+        }
+        self._plan = plan
+        return plan
+
+    def _valid(self, plan) -> bool:
+        return all(p.grad is not None and p.grad.data_ptr() == gp for (p, _), gp in zip(plan["entries"], plan["grad_ptrs"]))
+
+    def sync_hyperparameters(self) -> None:
+        """copy the per-group (lr, weight_decay) to the device table; call after a scheduler changed them (outside graph replay)."""
+        plan = self._plan or self._build()
+        host = [[float(g["lr"]), float(g["weight_decay"])] for g in self.param_groups]
+        if host != plan["hp_host"]:
+            plan["hp"].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)  # plumbing: 2 floats per group
+            plan["hp_host"] = host
+
+    @torch.no_grad()
+    def step(self, closure=None, inv_grad_scale: Optional[torch.Tensor] = None, sync_hyperparameters: bool = True):
+        loss = closure() if closure is not None else None
+        plan = self._plan
+        if plan is None or not self._valid(plan):
+            old = plan
+            plan = self._build()
+            if old is not None and old["total"] == plan["total"]:  # gradients were re-allocated: keep the moments
+                plan["m"], plan["v"], plan["step"] = old["m"], old["v"], old["step"]
+        if sync_hyperparameters:
+            self.sync_hyperparameters()
+        g0 = self.param_groups[0]
+        _lib.call("cvh_adamw_multi", _p(plan["table"]), plan["n"], plan["total"], _p(plan["m"]), _p(plan["v"]), _p(plan["hp"]),
+                  float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _p(plan["step"]), _p(inv_grad_scale),
+                  self.ema_momentum if self._ema is not None else 0.0, _stream())
+        return loss
+
+
+class EMABuffers:
+    """EMA of the model's floating-point BUFFERS (BatchNorm running statistics), the part of EMA.update_parameters that is not a
+    parameter (averaging_utils.py:47-55 iterates the whole state_dict); integer buffers (num_batches_tracked) are copied."""
+
+    def __init__(self, model: torch.nn.Module, ema_model: torch.nn.Module, momentum: float = 0.0005):
+        rows, off, self.ints = [], 0, []
+        for (k, s), (k2, d) in zip(model.named_buffers(), ema_model.named_buffers()):
+            if k != k2 or s.shape != d.shape:
+                raise RuntimeError("EMA model does not mirror the model's buffers")
+            if s.dtype == torch.float32:
+                rows.append([d.data_ptr(), s.data_ptr(), s.numel(), off])
+                off += s.numel()
+            else:
+                self.ints.append((d, s))
+        rows.append([0, 0, 0, off])
+        self.n, self.total, self.momentum = len(rows) - 1, off, float(momentum)
+        self.table = torch.tensor(rows, dtype=torch.int64, device=next(model.buffers()).device) if self.n else None
+        self._keep = (model, ema_model)
+
+    @torch.no_grad()
+    def update(self):
+        if self.n:
+            _lib.call("cvh_lerp_multi", _p(self.table), self.n, self.total, self.momentum, _stream())
+        for d, s in self.ints:  # averaging an integer counter is a copy after the cast back (ema_v.copy_(...) on an int64 tensor)
+            d.copy_((d * (1.0 - self.momentum) + self.momentum * s).to(d.dtype))

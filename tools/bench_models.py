@@ -85,7 +85,7 @@ def run(name, batch, steps, warmup, dtype, use_graph):
     if use_graph:
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 loss = one()
             graph = g
         except Exception as e:

@@ -33,17 +33,17 @@ def build(name, batch, dev):
         m = cvnets_amd.build_vit(name.split("_")[1], **{"model.classification.vit.dropout": 0.2 if name == "vit_base" else 0.0}).to(dev).train()
         x = torch.randn(batch, 3, 224, 224, device=dev)
         y = torch.randint(0, 1000, (batch,), device=dev)
-        return m, lambda: F.cross_entropy(m(x).float(), y, label_smoothing=0.1), "224x224"
+        return m, lambda: cvnets_amd.ops.cross_entropy(m(x), y, 0.1), "224x224"
     if name == "mobilevitv2":
         m = cvnets_amd.build_mobilevit_v2(1.0).to(dev).train()
         x = torch.randn(batch, 3, 384, 384, device=dev)
         y = torch.randint(0, 1000, (batch,), device=dev)
-        return m, lambda: F.cross_entropy(m(x).float(), y, label_smoothing=0.1), "384x384 width 1.0"
+        return m, lambda: cvnets_amd.ops.cross_entropy(m(x), y, 0.1), "384x384 width 1.0"
     if name == "mobilevit_s":
         m = cvnets_amd.build_mobilevit("small").to(dev).train()
         x = torch.randn(batch, 3, 256, 256, device=dev)
         y = torch.randint(0, 1000, (batch,), device=dev)
-        return m, lambda: F.cross_entropy(m(x).float(), y, label_smoothing=0.1), "256x256"
+        return m, lambda: cvnets_amd.ops.cross_entropy(m(x), y, 0.1), "256x256"
     if name == "clip":
         from cvnets_amd.layers import default_opts
         m = cvnets_amd.build_clip().to(dev).train()
@@ -65,15 +65,16 @@ def run(name, batch, steps, warmup, dtype, use_graph):
     ddp = DistributedDataParallel(model, bucket_cap_mb=25.0, broadcast_buffers=False)
     ddp.hooks_enabled = False
     cvnets_amd.ops.set_inplace_param_grads(True)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, fused=True, capturable=True)
+    opt = cvnets_amd.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
 
     def one():
         ddp.zero_grad()
         loss = loss_of()
         loss.backward()
-        opt.step()
+        opt.step(sync_hyperparameters=not capturing[0])
         return loss
 
+    capturing = [False]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -85,6 +86,7 @@ def run(name, batch, steps, warmup, dtype, use_graph):
     if use_graph:
         try:
             g = torch.cuda.CUDAGraph()
+            capturing[0] = True
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 loss = one()
             graph = g
@@ -119,6 +121,76 @@ def run(name, batch, steps, warmup, dtype, use_graph):
     return out
 
 
+def run_vbs(steps, warmup, dtype):
+    """BASELINE config 5: MobileViTv2-1.0 under the variable-batch-sampler schedule around 384^2 — the (H = W, B) pairs of
+    data/sampler/utils.py:13-67 image_batch_pairs(384, 384, 128, min 256, max 512, 5 scales, divisor 32), drawn per step with
+    random.seed(epoch) as data/sampler/variable_batch_sampler.py:315-320 does.  One hipGraph per shape, captured on first use
+    (capture time is inside the timed region: no per-shape warm-up credit)."""
+    import random
+
+    import cvnets_amd
+    from cvnets_amd.ddp import DistributedDataParallel
+
+    pairs = [(256, 288), (320, 184), (384, 128), (448, 94), (512, 72)]
+    dev = torch.device("cuda", 0)
+    cvnets_amd.set_compute_dtype(dtype)
+    torch.manual_seed(1234)
+    m = cvnets_amd.build_mobilevit_v2(1.0).to(dev).train()
+    ddp = DistributedDataParallel(m, bucket_cap_mb=25.0, broadcast_buffers=False)
+    ddp.hooks_enabled = False
+    cvnets_amd.ops.set_inplace_param_grads(True)
+    opt = cvnets_amd.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+    data = {hw: (torch.randn(b, 3, hw, hw, device=dev), torch.randint(0, 1000, (b,), device=dev)) for hw, b in pairs}
+    graphs = {}
+
+    def one(hw):
+        x, y = data[hw]
+        ddp.zero_grad()
+        loss = cvnets_amd.ops.cross_entropy(m(x), y, 0.1)
+        loss.backward()
+        opt.step(sync_hyperparameters=False)
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ddp.zero_grad()
+        cvnets_amd.ops.cross_entropy(m(data[256][0][:8]), data[256][1][:8], 0.1).backward()
+        opt.step()  # builds the optimizer tables (eager, tiny batch)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    rng = random.Random(0)
+    seq = [rng.choice(pairs) for _ in range(warmup + steps)]
+
+    def step(hw):
+        if hw not in graphs:
+            s2 = torch.cuda.Stream()
+            s2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s2):
+                one(hw)  # allocator warm-up for this shape
+            torch.cuda.current_stream().wait_stream(s2)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                one(hw)
+            graphs[hw] = g
+        graphs[hw].replay()
+
+    for hw, _ in seq[:warmup]:
+        step(hw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    imgs = 0
+    for hw, b in seq[warmup:]:
+        step(hw)
+        imgs += b
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    cvnets_amd.ops.set_inplace_param_grads(False)
+    return {"model": "mobilevitv2_vbs", "workload": f"MobileViTv2-1.0, VBS schedule {pairs}, {steps} steps after {warmup} (graphs captured on first use of a shape)",
+            "dtype": str(dtype).split(".")[-1], "images_per_sec": round(imgs / wall, 1), "ms_per_step": round(wall * 1e3 / steps, 3),
+            "shapes_seen": sorted({hw for hw, _ in seq}), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "bound": "hbm"}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--models", default="vit_base,mobilevitv2,clip")
@@ -130,6 +202,12 @@ if __name__ == "__main__":
     a = ap.parse_args()
     batches = dict(kv.split("=") for kv in a.batch.split(","))
     for name in a.models.split(","):
+        if name == "mobilevitv2_vbs":
+            try:
+                print(json.dumps(run_vbs(a.steps, a.warmup, torch.bfloat16 if a.dtype == "bf16" else torch.float32)), flush=True)
+            except Exception as e:
+                print(json.dumps({"model": name, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
+            continue
         try:
             print(json.dumps(run(name, int(batches[name]), a.steps, a.warmup, torch.bfloat16 if a.dtype == "bf16" else torch.float32, not a.no_graph)), flush=True)
         except Exception as e:  # keep going: one model failing must not hide the others

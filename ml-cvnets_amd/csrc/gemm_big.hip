@@ -16,9 +16,9 @@
 #include "gemm_params.hpp"
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;      // 16 KB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;     // 16 KB per 128-row operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;    // A + B of the 128 x 128 kernels
 constexpr int STG_PITCH = 64 + 8;            // bf16 elements per staged output row (64 columns + 16 B pad)
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -35,7 +35,14 @@ __device__ __forceinline__ Frag<bf16_t> frag_swz(const unsigned char* tile, int 
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(ConvGemmParams p) {
+// WM = wave rows: tile = (64*WM) x 128, 2*WM waves.  WM = 2: 128x128, 64 KB LDS, 2 workgroups per CU.  WM = 4: 256x128, 96 KB LDS, one
+// 8-wave workgroup per CU — same waves per CU, but 1.33x the MFMA work per byte brought into LDS (the kernel is bound by the bytes
+// it can keep in flight towards LDS: ~1.5 us of L2/HBM latency x 2 tile buffers).
+template <int WM>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(ConvGemmParams p) {
+  constexpr int BM = 64 * WM;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int NB = 8 / WM;  // B-tile instructions per wave
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ONE LDS object: 2 x (A tile | B tile); reused by the epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -58,16 +65,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(ConvGemmParams p) {
     int am = m0 + row;
     if (am > M - 1) am = M - 1;  // rows past M: read a valid row, the result is never stored
     ga[j] = A + (size_t)am * K + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int row = (wave * NB + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
     gb[j] = Wp + (size_t)(n0 + row) * K + c * 8;
   }
   auto issue = [&](int kt, int buf) {
     unsigned char* a_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024;
-    unsigned char* b_dst = a_dst + TILE_BYTES;
+    unsigned char* b_dst = smem + buf * BUF_BYTES + A_BYTES + (wave * NB) * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      glds16(ga[j] + kt * BK, a_dst + j * 1024);
-      glds16(gb[j] + kt * BK, b_dst + j * 1024);
-    }
+    for (int j = 0; j < 4; ++j) glds16(ga[j] + kt * BK, a_dst + j * 1024);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) glds16(gb[j] + kt * BK, b_dst + j * 1024);
   };
 
   f32x16_t acc[2][2];
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(ConvGemmParams p) {
     const int buf = kt & 1;
     if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
     const unsigned char* At = smem + buf * BUF_BYTES;
-    const unsigned char* Bt = At + TILE_BYTES;
+    const unsigned char* Bt = At + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       const int chunk = 2 * kk + (lane >> 5);
@@ -159,10 +170,21 @@ bool gemm_big_eligible(const ConvGemmParams& p) {
 
 int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
   ConvGemmParams p = p0;
-  p.m_tiles = (p.M + BM - 1) / BM;
-  const int total = p.m_tiles * (p.N / BN);
-  constexpr int smem = 2 * BUF_BYTES;  // 64 KB: two workgroups per CU
-  hipLaunchKernelGGL(gemm_nt128_kernel, dim3(total), dim3(256), smem, st, p);
+  if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 2 && p.M >= 8192) {  // 256 x 128 tiles, one 8-wave workgroup per CU
+    p.m_tiles = (p.M + 255) / 256;
+    constexpr int smem = 2 * (256 + 128) * BK * 2;  // 96 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt128_kernel<4>, dim3(p.m_tiles * (p.N / BN)), dim3(512), smem, st, p);
+  } else {
+    p.m_tiles = (p.M + 127) / 128;
+    constexpr int smem = 2 * BUF_BYTES;  // 64 KB: two workgroups per CU
+    hipLaunchKernelGGL(gemm_nt128_kernel<2>, dim3(p.m_tiles * (p.N / BN)), dim3(256), smem, st, p);
+  }
   CVH_CHECK_LAUNCH();
   return 0;
 }

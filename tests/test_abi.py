@@ -67,3 +67,10 @@ def test_ops_refuse_to_run_without_gpu():
         ops.linear(torch.zeros(8, 8), torch.zeros(8, 8))
     with pytest.raises(RuntimeError):
         ops.to_nhwc(torch.zeros(1, 3, 4, 4))
+    with pytest.raises(RuntimeError):
+        ops.cross_entropy(torch.zeros(4, 10), torch.zeros(4, dtype=torch.long), 0.1)
+    from cvnets_amd.optim import AdamW
+    w = torch.nn.Parameter(torch.zeros(8))
+    w.grad = torch.zeros(8)
+    with pytest.raises(RuntimeError):
+        AdamW([w], lr=1e-3).step()

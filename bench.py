@@ -242,8 +242,18 @@ def main():
             "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMG,
             "gpu_ms_per_step_hip_events": round(gpu_ms_per_step, 3),
         }
+        pmc = None
+        try:  # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 PMC passes of this command
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            if args.batch == pmc["step"]["images"] and args.mode == "small" and args.res == 256 and args.dtype == "bf16":
+                roofline["traffic"] = pmc["step"]["total_bytes"] / pmc["step"]["images"]  # bytes per image, like algorithmic_bytes_per_image
+                roofline["traffic_source"] = pmc["source"]
+        except Exception:
+            pmc = None
         try:
             roofline["dominant_kernel"] = dominant_kernel_probe(dtype, args.batch)
+            if pmc is not None and args.batch == 128:
+                roofline["dominant_kernel"]["traffic"] = pmc["dominant_kernel"]["read_bytes_per_launch"] + pmc["dominant_kernel"]["write_bytes_per_launch"]
             roofline["dominant_kernel"]["frac"] = round(roofline["dominant_kernel"]["achieved_GBps"] * 1e9 / HBM_PEAK, 4)
         except Exception as e:  # pragma: no cover
             roofline["dominant_kernel"] = {"error": str(e)[:200]}

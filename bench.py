@@ -172,6 +172,8 @@ def main():
         for _ in range(2):
             zero_grads()
             static_loss = fwd_bwd()
+            if world > 1:
+                ddp.allreduce_flat()  # replicas stay identical through the warm-up as well
             if opt is not None:
                 opt.step()
     torch.cuda.current_stream().wait_stream(side)

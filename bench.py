@@ -107,14 +107,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CVH_BENCH_SHARE_GPU=1 + CVH_DIST_BACKEND=gloo: developer rehearsal of the N > 1 control flow on a 1-GPU box (all ranks on cuda:0,
+    # host-staged collectives); the real runs use one GPU per rank and RCCL.
+    dev_index = 0 if os.environ.get("CVH_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import cvnets_amd
     from cvnets_amd.ddp import DistributedDataParallel, distributed_init
 
     if world > 1:
-        distributed_init("nccl", dev)
+        distributed_init(os.environ.get("CVH_DIST_BACKEND", "nccl"), dev)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cvnets_amd.set_compute_dtype(dtype)
     torch.manual_seed(1234 + rank)

@@ -124,6 +124,16 @@ int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void*
 int cvh_resize_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream);
 int cvh_resize_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int Ho, int Wo, int C, int align_corners, void* stream);
 
+/* The reference LayerNorm's channel-first branch as it fires on a [B', S, C] token tensor with S == C
+ * (cvnets/layers/normalization/layer_norm.py:53-66): statistics per (sequence, channel) over the S tokens, (std + eps) denominator,
+ * gamma / beta indexed by the token position.  Sequences are addressed through the (ph, pw, n_w, H, W) row map of cvh_attn_*.
+ * stats[nseq][2][C] = (mean, std) is written by fwd and read by bwd; part[nseq][2][S] receives each sequence's contribution to
+ * (dgamma, dbeta) — sum over its nseq rows with cvh_sum_partials. */
+int cvh_ln_seq_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, int nseq, int S, int C, int ph,
+                   int pw, int n_w, int H, int W, float eps, void* stream);
+int cvh_ln_seq_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats, void* dx, float* part, int nseq, int S,
+                   int C, int ph, int pw, int n_w, int H, int W, float eps, void* stream);
+
 /* ---- CLIP heads and loss ------------------------------------------------------------------------- */
 /* dst[r] = src[idx[r]] (scatter == 0) / dst[idx[r]] = src[r] (scatter == 1, dst pre-zeroed): the EOT-token gather
  * token_emb[arange(B), text_tokens.argmax(-1)] (cvnets/text_encoders/transformer.py:413-421) and its adjoint. */

@@ -16,9 +16,6 @@
 #include "common.hpp"
 #include "cvnets_hip.h"
 
-struct SeqMap {
-  int ph, pw, n_w, H, W;
-};
 struct AttnParams {
   const void* qkv;   // T [rows][3d]
   void* out;         // fwd: T [rows][d]
@@ -33,13 +30,6 @@ struct AttnParams {
   int causal;
 };
 
-__device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
-  const int P = m.ph * m.pw;
-  const int b = s / P, pi = s - b * P;
-  const int i = pi / m.pw, j = pi - i * m.pw;
-  const int nh = n / m.n_w, nw = n - nh * m.n_w;
-  return (b * m.H + nh * m.ph + i) * m.W + nw * m.pw + j;
-}
 
 template <typename T, int VEC> __device__ __forceinline__ void ld_vec(const T* p, float* f) {
   if (VEC == 4) {

@@ -251,6 +251,20 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
+// Row map of a token "sequence" on an NHWC feature map (MobileViTBlock.unfolding, cvnets/modules/mobilevit_block.py:186-231, as index
+// arithmetic): row(s, n) = (b*H + nh*ph + i)*W + nw*pw + j with s = b*ph*pw + i*pw + j, n = nh*n_w + nw.  ph = pw = 1, H = 1,
+// W = n_w = S is the plain contiguous [B][S][d] case.
+struct SeqMap {
+  int ph, pw, n_w, H, W;
+};
+__device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
+  const int P = m.ph * m.pw;
+  const int b = s / P, pi = s - b * P;
+  const int i = pi / m.pw, j = pi - i * m.pw;
+  const int nh = n / m.n_w, nw = n - nh * m.n_w;
+  return (b * m.H + nh * m.ph + i) * m.W + nw * m.pw + j;
+}
+
 // run-time tuning knobs (A/B experiments from tools/kernel_bench.py; defaults = shipped configuration)
 #define CVH_TUNE_TN_PITCH 1      /* 0: 80-byte rows + ds_read_b128, 1: 72-byte rows + 2 x ds_read_b64 */
 #define CVH_TUNE_TN_WGS 2        /* target number of gemm_tn workgroups */

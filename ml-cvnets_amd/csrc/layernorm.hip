@@ -164,3 +164,180 @@ extern "C" int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const
   CVH_CHECK_LAUNCH();
   return 0;
 }
+
+// =============================================================================================
+// The reference's channel-first LayerNorm branch applied to a [B', S, C] token tensor with S == C
+// (cvnets/layers/normalization/layer_norm.py:53-66 fires whenever x.shape[1] == C and x.ndim > 2 — e.g. MobileViT-S at 192x192
+// (144 patches x 144 channels) or MobileViT-XXS at 128x128 (64 x 64), SURVEY.md headline fact 5):
+//     u, s = mean / biased std over dim 1 (the PATCH axis) ;  y[b,n,c] = beta[n] + gamma[n] * (x[b,n,c] - u[b,c]) / (s[b,c] + eps)
+// i.e. statistics per (sequence, channel) over the tokens, affine indexed by the token position, and (std + eps) rather than
+// sqrt(var + eps).  Bug-compatible by default so that results stay identical to the reference at every resolution.
+// One workgroup per sequence; thread = (8-channel group, row lane); rows are gathered through the SeqMap.
+// =============================================================================================
+struct LnSeqParams {
+  int nseq, S, C;
+  SeqMap map;
+  float eps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_seq_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ y, float* __restrict__ stats /* [nseq][2][C]: mean, std */, LnSeqParams p) {
+  extern __shared__ float sm[];  // red[RL][2][C] | mu[C] | inv_t[C]
+  const int cg = p.C / 8, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int s = blockIdx.x;
+  float* red = sm;
+  float* mu = sm + RL * 2 * p.C;
+  float* it = mu + p.C;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL) {
+    for (int n = rl; n < p.S; n += RL) {
+      float f[8];
+      v8_unpack(v8_load<T>(x + (size_t)seq_row(p.map, s, n) * p.C + g * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a[j] += f[j]; q[j] += f[j] * f[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(rl * 2) * p.C + g * 8 + j] = a[j]; red[(rl * 2 + 1) * p.C + g * 8 + j] = q[j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int l = 0; l < RL; ++l) { s1 += red[(l * 2) * p.C + c]; s2 += red[(l * 2 + 1) * p.C + c]; }
+    const double m = s1 / p.S;
+    double var = s2 / p.S - m * m;
+    if (var < 0.0) var = 0.0;
+    const float sd = (float)sqrt(var);
+    mu[c] = (float)m;
+    it[c] = 1.0f / (sd + p.eps);
+    stats[((size_t)s * 2) * p.C + c] = (float)m;
+    stats[((size_t)s * 2 + 1) * p.C + c] = sd;
+  }
+  __syncthreads();
+  if (rl < RL) {
+    float m8[8], i8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m8[j] = mu[g * 8 + j]; i8[j] = it[g * 8 + j]; }
+    for (int n = rl; n < p.S; n += RL) {
+      const size_t row = (size_t)seq_row(p.map, s, n);
+      const float ga = gamma[n], be = beta[n];
+      float f[8];
+      v8_unpack(v8_load<T>(x + row * p.C + g * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = be + ga * ((f[j] - m8[j]) * i8[j]);
+      V8<T> o;
+      v8_pack(f, o);
+      v8_store<T>(y + row * p.C + g * 8, o);
+    }
+  }
+}
+
+// z = (x-u)/t, t = s + eps, g = dy * gamma[n]:  dx = (g - mean_n g)/t - (z/s) * mean_n(g z)
+// part[s][2][S]: per-sequence contributions to dgamma[n] = sum_c dy z and dbeta[n] = sum_c dy (summed over sequences by cvh_sum_partials)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_seq_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                         const float* __restrict__ stats, T* __restrict__ dx, float* __restrict__ part, LnSeqParams p) {
+  extern __shared__ float sm[];  // red[RL][2][C] | mg[C] | mgz[C] | rowacc[2][S]
+  const int cg = p.C / 8, RL = 256 / cg;
+  const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+  const int s = blockIdx.x;
+  float* red = sm;
+  float* mg = sm + RL * 2 * p.C;
+  float* mgz = mg + p.C;
+  float* rowacc = mgz + p.C;
+  for (int i = threadIdx.x; i < 2 * p.S; i += 256) rowacc[i] = 0.f;
+  float m8[8], s8[8], i8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    m8[j] = stats[((size_t)s * 2) * p.C + g * 8 + j];
+    s8[j] = stats[((size_t)s * 2 + 1) * p.C + g * 8 + j];
+    i8[j] = 1.0f / (s8[j] + p.eps);
+  }
+  __syncthreads();
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < RL) {
+    for (int n = rl; n < p.S; n += RL) {
+      const size_t row = (size_t)seq_row(p.map, s, n);
+      const float ga = gamma[n];
+      float f[8], d[8];
+      v8_unpack(v8_load<T>(x + row * p.C + g * 8), f);
+      v8_unpack(v8_load<T>(dy + row * p.C + g * 8), d);
+      float dg = 0.f, db = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = (f[j] - m8[j]) * i8[j];
+        a[j] += d[j] * ga;
+        q[j] += d[j] * ga * z;
+        dg += d[j] * z;
+        db += d[j];
+      }
+      atomicAdd(&rowacc[n], dg);
+      atomicAdd(&rowacc[p.S + n], db);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(rl * 2) * p.C + g * 8 + j] = a[j]; red[(rl * 2 + 1) * p.C + g * 8 + j] = q[j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int l = 0; l < RL; ++l) { s1 += red[(l * 2) * p.C + c]; s2 += red[(l * 2 + 1) * p.C + c]; }
+    mg[c] = s1 / (float)p.S;
+    mgz[c] = s2 / (float)p.S;
+  }
+  for (int i = threadIdx.x; i < 2 * p.S; i += 256) part[(size_t)s * 2 * p.S + i] = rowacc[i];
+  __syncthreads();
+  if (rl < RL) {
+    float g8[8], z8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { g8[j] = mg[g * 8 + j]; z8[j] = s8[j] > 0.f ? mgz[g * 8 + j] / s8[j] : 0.f; }
+    for (int n = rl; n < p.S; n += RL) {
+      const size_t row = (size_t)seq_row(p.map, s, n);
+      const float ga = gamma[n];
+      float f[8], d[8];
+      v8_unpack(v8_load<T>(x + row * p.C + g * 8), f);
+      v8_unpack(v8_load<T>(dy + row * p.C + g * 8), d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = (f[j] - m8[j]) * i8[j];
+        f[j] = (d[j] * ga - g8[j]) * i8[j] - z * z8[j];
+      }
+      V8<T> o;
+      v8_pack(f, o);
+      v8_store<T>(dx + row * p.C + g * 8, o);
+    }
+  }
+}
+
+static int ln_seq_params(LnSeqParams& p, int nseq, int S, int C, int ph, int pw, int n_w, int H, int W, float eps) {
+  if (C % 8 || C < 8 || C > 2048 || S != C || nseq <= 0) return -2;  // gamma/beta [C] are indexed by the token position: needs S == C
+  p.nseq = nseq; p.S = S; p.C = C; p.eps = eps;
+  p.map.ph = ph; p.map.pw = pw; p.map.n_w = n_w; p.map.H = H; p.map.W = W;
+  return 0;
+}
+extern "C" int cvh_ln_seq_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, int nseq, int S, int C, int ph,
+                              int pw, int n_w, int H, int W, float eps, void* stream) {
+  LnSeqParams p;
+  if (ln_seq_params(p, nseq, S, C, ph, pw, n_w, H, W, eps)) return -2;
+  const int RL = 256 / (C / 8);
+  const size_t smem = (size_t)(RL * 2 * C + 2 * C) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_seq_fwd_kernel<bf16_t>), dim3(nseq), dim3(256), smem, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, stats, p);
+  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_seq_fwd_kernel<float>), dim3(nseq), dim3(256), smem, st, (const float*)x, gamma, beta, (float*)y, stats, p);
+  else return -1;
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_ln_seq_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats, void* dx, float* part, int nseq, int S,
+                              int C, int ph, int pw, int n_w, int H, int W, float eps, void* stream) {
+  LnSeqParams p;
+  if (ln_seq_params(p, nseq, S, C, ph, pw, n_w, H, W, eps)) return -2;
+  const int RL = 256 / (C / 8);
+  const size_t smem = (size_t)(RL * 2 * C + 2 * C + 2 * S) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_seq_bwd_kernel<bf16_t>), dim3(nseq), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, stats, (bf16_t*)dx, part, p);
+  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_seq_bwd_kernel<float>), dim3(nseq), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, stats, (float*)dx, part, p);
+  else return -1;
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

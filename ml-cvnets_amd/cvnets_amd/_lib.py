@@ -58,6 +58,8 @@ SIGNATURES = {
     "cvh_l2norm_bwd": [I, P, P, P, P, I, I, F, P],
     "cvh_scaled_ce_fwd": [I, P, P, P, P, I, I, I, P],
     "cvh_scaled_ce_bwd": [I, P, P, P, P, P, P, I, I, I, P],
+    "cvh_ln_seq_fwd": [I, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P],
+    "cvh_ln_seq_bwd": [I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, F, P],
     "cvh_adamw_multi": [P, I, L, P, P, P, F, F, F, P, P, F, P],
     "cvh_lerp_multi": [P, I, L, F, P],
     "cvh_ce_fwd": [I, P, P, F, L, P, P, I, I, P],

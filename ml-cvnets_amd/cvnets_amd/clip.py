@@ -102,7 +102,7 @@ class TextTransformer(nn.Module):
         for layer in self.transformer:
             t = layer.forward_tokens(t, seqmap, causal=causal, key_padding_mask=key_padding_mask)
         n = self.final_layer_norm
-        t = ops.layer_norm(t, n.weight, n.bias, n.eps)
+        t = ops.layer_norm_tokens(t, n, seqmap)
         if return_all_tokens:
             return t.view(B, S, self.model_dim)
         rows = torch.arange(B, device=text_tokens.device) * S + text_tokens.argmax(dim=-1)  # plumbing: EOT index arithmetic

@@ -123,17 +123,25 @@ class BatchNorm2d(nn.BatchNorm2d):
 
 
 class LayerNorm(nn.LayerNorm):
-    """cvnets/layers/normalization/layer_norm.py:14-72.  The channel-last branch (:67-68) is the HIP kernel.  The
-    reference's channel-first branch (:53-66, taken whenever x.shape[1] == C and ndim > 2 — also, by accident, for a
-    [B', S, C] token tensor with S == C) is NOT reproduced: it is rejected loudly (see DESIGN.md "LayerNorm quirk")."""
+    """cvnets/layers/normalization/layer_norm.py:14-72.  The channel-last branch (:67-68) is cvh_layernorm_*.  The reference's
+    channel-first branch (:53-66) is taken whenever ``x.shape[1] == C and x.ndim > 2`` — which also happens, by accident, for a
+    [B', S, C] token tensor with S == C (MobileViT-S at 192x192, MobileViT-XXS at 128x128).  That case is reproduced bug-compatibly
+    (cvh_ln_seq_*, ``reference_quirk = True``); set ``reference_quirk = False`` for the documented channel-last LayerNorm.  A
+    genuine NCHW feature map through this class is rejected (not on the hot path)."""
+
+    reference_quirk = True
 
     def __init__(self, normalized_shape, eps: Optional[float] = 1e-5, elementwise_affine: Optional[bool] = True, *args, **kwargs):
         super().__init__(normalized_shape=normalized_shape, eps=eps, elementwise_affine=elementwise_affine)
 
     def forward(self, x: Tensor) -> Tensor:
         c = self.normalized_shape[0]
+        if x.ndim == 3 and x.shape[1] == c and x.shape[2] == c:
+            b, s, _ = x.shape
+            y = ops.layer_norm_tokens(x.reshape(b * s, c).contiguous(), self, (b, s, 1, 1, s, 1, s))
+            return y.view(b, s, c)
         if x.ndim > 2 and x.shape[1] == c and x.shape[-1] != c:
-            raise NotImplementedError("channel-first LayerNorm is not on the HIP hot path")
+            raise NotImplementedError("channel-first LayerNorm of a feature map is not on the HIP hot path")
         if x.shape[-1] != c:
             raise NotImplementedError("LayerNorm is supported for channel-last format only")
         shp = x.shape

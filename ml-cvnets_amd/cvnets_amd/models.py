@@ -226,7 +226,7 @@ class VisionTransformer(nn.Module):
         for layer in self.transformer:
             t = layer.forward_tokens(t, seqmap)
         n = self.post_transformer_norm
-        t = ops.layer_norm(t, n.weight, n.bias, n.eps)
+        t = ops.layer_norm_tokens(t, n, seqmap)
         if self.cls_token is None:
             raise NotImplementedError("mean-pooled ViT (no_cls_token) is not on the HIP hot path")
         return ops.RowsGather.apply(t, B, S, 0), None

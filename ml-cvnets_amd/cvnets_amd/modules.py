@@ -116,10 +116,10 @@ class TransformerEncoder(nn.Module):
         if drop_ffn.p > 0.0 and self.training:
             raise NotImplementedError("ffn_dropout > 0 is not fused (reference YAMLs use 0.0)")
         # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue
-        y = ops.layer_norm(x, ln1.weight, ln1.bias, ln1.eps)
+        y = ops.layer_norm_tokens(x, ln1, seqmap)
         x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x)
         # x = x + Dropout(W2 act(W1 LN(x)))
-        y = ops.layer_norm(x, ln2.weight, ln2.bias, ln2.eps)
+        y = ops.layer_norm_tokens(x, ln2, seqmap)
         h = ops.linear(y, fc1.weight, fc1.bias, act=act_code(act))
         return ops.linear(h, fc2.weight, fc2.bias, drop_p=p2, residual=x)
 
@@ -209,7 +209,7 @@ class MobileViTBlock(nn.Module):
             else:
                 if not isinstance(layer, nn.LayerNorm):
                     raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
-                t = ops.layer_norm(t, layer.weight, layer.bias, layer.eps)
+                t = ops.layer_norm_tokens(t, layer, seqmap)
         fm = ops.fmap_of(t, B, H, W)
         if interpolate:  # ... and back to the original size after folding (mobilevit_block.py:260-266)
             fm = ops.resize_bilinear(fm, H0, W0)

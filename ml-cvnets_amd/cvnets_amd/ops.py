@@ -708,6 +708,50 @@ def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# reference quirk: channel-first LayerNorm branch hit by [B', S, C] token tensors with S == C
+# ------------------------------------------------------------------------------------------------
+class LayerNormSeqFn(torch.autograd.Function):
+    """cvnets/layers/normalization/layer_norm.py:53-66 as the reference evaluates it on a token tensor whose sequence length equals
+    its channel count: (x - mean_over_tokens) / (std_over_tokens + eps), weight / bias indexed by the TOKEN position."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, seqmap):
+        _check_dev(x)
+        nseq, S, ph, pw, n_w, H, W = seqmap
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        stats = _f32(nseq * 2 * C, x.device)
+        _lib.call("cvh_ln_seq_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), nseq, S, C, ph, pw, n_w, H, W, float(eps), _stream())
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.cfg = (float(eps), tuple(seqmap))
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, stats = ctx.saved_tensors
+        eps, seqmap = ctx.cfg
+        nseq, S, ph, pw, n_w, H, W = seqmap
+        C = x.shape[1]
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        part = _f32(nseq * 2 * S, x.device)
+        _lib.call("cvh_ln_seq_bwd", _dt(x), _p(x), _p(dout), _p(gamma), _p(stats), _p(dx), _p(part), nseq, S, C, ph, pw, n_w, H, W, eps, _stream())
+        dgb = _f32(2 * S, x.device)
+        _lib.call("cvh_sum_partials", _p(part), nseq, 2 * S, 2 * S, _p(dgb), 1.0, 0, _stream())
+        return dx, dgb[:S], dgb[S:], None, None
+
+
+def layer_norm_tokens(x2d, ln, seqmap):
+    """LayerNorm of a token matrix whose sequences are described by `seqmap`, reproducing WHICH branch the reference's LayerNorm
+    takes for the equivalent [B', S, C] tensor: channel-last F.layer_norm normally, the channel-first formula when S == C
+    (layer_norm.py:51-68).  `ln.reference_quirk = False` opts out (always the documented channel-last LayerNorm)."""
+    S, C = seqmap[1], x2d.shape[1]
+    if S == C and getattr(ln, "reference_quirk", True):
+        return LayerNormSeqFn.apply(x2d, ln.weight, ln.bias, float(ln.eps), tuple(int(v) for v in seqmap))
+    return layer_norm(x2d, ln.weight, ln.bias, ln.eps)
+
+
+# ------------------------------------------------------------------------------------------------
 # LayerNorm over the last dim of a token matrix
 # ------------------------------------------------------------------------------------------------
 class LayerNormFn(torch.autograd.Function):

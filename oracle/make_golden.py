@@ -39,6 +39,8 @@ CASES = [
     ("mobilevit_s_128_b2", "small", 2, 128),
     ("mobilevit_s_256_b2", "small", 2, 256),
     ("mobilevit_s_160_b2", "small", 2, 160),   # VBS resolution (mobilevit.yaml sampler 160..320)
+    # layer_3 sees 64 patches x 64 channels: the reference LayerNorm takes its channel-first branch (layer_norm.py:53-66)
+    ("mobilevit_xxs_128_b2", "xx_small", 2, 128),
 ]
 FULL_GRADS = [
     "conv_1.block.conv.weight", "conv_1.block.norm.weight", "conv_1.block.norm.bias",

@@ -408,3 +408,46 @@ def test_resize_bilinear(ops, dtype, H, W, Ho, Wo):
     (g,) = torch.autograd.grad(y, [x], go)
     (r,) = torch.autograd.grad(ref, [xr], go.float())
     check("resize bwd", g, r, dtype, scale=2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(3, 64, 1, 1), (2, 144, 2, 2), (5, 24, 1, 1), (1, 64, 2, 2)])
+def test_layer_norm_reference_quirk(ops, dtype, cfg):
+    """S == C token tensors: the reference's LayerNorm normalises over the TOKEN axis with (std + eps) and token-indexed affine
+    (cvnets/layers/normalization/layer_norm.py:53-66); cvh_ln_seq_* must reproduce exactly that, on contiguous sequences and on
+    sequences gathered from an NHWC map (MobileViT unfolding)."""
+    from cvnets_amd.layers import LayerNorm
+
+    B, C, ph, pw = cfg
+    S = C
+    torch.manual_seed(0)
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C) * 0.5 + 1.0)
+        ln.bias.copy_(torch.randn(C) * 0.1)
+    if ph == 1:
+        H, W, n_w = 1, S, S
+    else:  # S patches of ph x pw pixels: feature map (n_h*ph) x (n_w*pw) with n_h*n_w == S
+        n_w = int(round(S ** 0.5)) if int(round(S ** 0.5)) ** 2 == S else S // 8
+        H, W = (S // n_w) * ph, n_w * pw
+    rows = B * H * W
+    x = _rand(rows, C, seed=3).to(dtype).requires_grad_(True)
+    seqmap = (B * ph * pw, S, ph, pw, n_w, H, W)
+    y = ops.layer_norm_tokens(x, ln, seqmap)
+    # reference formula on the explicitly unfolded [B', S, C] tensor
+    xr = x.detach().float().requires_grad_(True)
+    fm = xr.view(B, H // ph, ph, W // pw, pw, C).permute(0, 2, 4, 1, 3, 5).reshape(B * ph * pw, S, C)  # [b*P + i*pw + j, nh*n_w + nw, c]
+    wr, br = ln.weight.detach().clone().requires_grad_(True), ln.bias.detach().clone().requires_grad_(True)
+    sd, mu = torch.std_mean(fm, dim=1, keepdim=True, unbiased=False)
+    ref = torch.addcmul(br.reshape(1, C, 1), (fm - mu) / (sd + ln.eps), wr.reshape(1, C, 1))
+    ref_rows = ref.view(B, ph, pw, H // ph, W // pw, C).permute(0, 3, 1, 4, 2, 5).reshape(rows, C)
+    check("ln quirk fwd", y, ref_rows, dtype)
+    go = _rand(rows, C, seed=4).to(dtype)
+    gx, gw, gb = torch.autograd.grad(y, [x, ln.weight, ln.bias], go)
+    rx, rw, rb = torch.autograd.grad(ref_rows, [xr, wr, br], go.float())
+    check("ln quirk dx", gx, rx, dtype, scale=3)
+    check("ln quirk dgamma", gw, rw, dtype, scale=3)
+    check("ln quirk dbeta", gb, rb, dtype, scale=3)
+    ln.reference_quirk = False  # opt-out: the documented channel-last LayerNorm
+    y2 = ops.layer_norm_tokens(x, ln, seqmap)
+    check("ln no-quirk", y2, F.layer_norm(x.detach().float(), (C,), ln.weight.detach(), ln.bias.detach(), ln.eps), dtype)

@@ -24,7 +24,9 @@ pytestmark = pytest.mark.gpu
 BF16_SLACK = 1.5
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = [("mobilevit_xxs_32_b8", "xx_small", 8, 32), ("mobilevit_s_128_b2", "small", 2, 128), ("mobilevit_s_256_b2", "small", 2, 256),
-         ("mobilevit_s_160_b2", "small", 2, 160)]
+         ("mobilevit_s_160_b2", "small", 2, 160),
+         # 64 patches x 64 channels in layer_3: the reference LayerNorm takes its channel-first branch; reproduced bug-compatibly (cvh_ln_seq_*)
+         ("mobilevit_xxs_128_b2", "xx_small", 2, 128)]
 
 
 def _build(mode, dtype):

@@ -27,3 +27,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+if os.environ.get("CVH_TEST_NAN_FILL"):
+    # debugging aid: every torch.empty() buffer starts as NaN (floats) / max-int, so a kernel that reads memory it was supposed to
+    # write first poisons the result deterministically instead of depending on what the caching allocator handed out
+    import torch
+
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True

@@ -57,6 +57,20 @@ def test_library_exports_every_declared_symbol():
         _lib.query("cvh_colreduce_rows", 1000, 20)  # C % 8 != 0 is rejected
 
 
+def test_dw_split_planner_fills_whole_rounds():
+    """host-side planning of the transformer-sized dW GEMM (csrc/gemm.hip tn_plan, no GPU needed): scratch = splits * N * K floats;
+    the split count must make (output tiles x splits) land just under a multiple of the 512 workgroup slots instead of just over."""
+    from cvnets_amd import _lib
+    M = 128 * 197  # ViT-B tokens at batch 128
+    for N, K, tiles in ((3072, 768, 144), (768, 768, 36), (2304, 768, 108), (768, 3072, 144)):
+        splits = _lib.query("cvh_gemm_dw_scratch_elems", M, N, K) // (N * K)
+        rounds = tiles * splits / 512.0
+        assert 1 <= splits <= 32 and (N * K * splits) == _lib.query("cvh_gemm_dw_scratch_elems", M, N, K)
+        assert rounds <= 1.0 or (rounds % 1.0) >= 0.85 or (rounds % 1.0) == 0.0, (N, K, splits, rounds)
+    # small conv-style problems keep the many-split plan (tall-skinny dW: one 128x128 tile, reduction over 2M pixels)
+    assert _lib.query("cvh_gemm_dw_scratch_elems", 128 * 128 * 128, 128, 32) // (128 * 32) >= 256
+
+
 def test_ops_refuse_to_run_without_gpu():
     """the product path has no CPU fallback: calling an op on CPU tensors raises instead of silently computing."""
     import torch

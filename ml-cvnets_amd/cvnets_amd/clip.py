@@ -87,7 +87,7 @@ class TextTransformer(nn.Module):
         nn.init.normal_(self.projection_layer, mean=0.0, std=attn_std)
 
     def forward_embedding(self, text_tokens: Tensor) -> Tensor:
-        pos = self.positional_embedding(text_tokens.shape[1]) if self.positional_embedding is not None else None
+        pos = self.positional_embedding.table(text_tokens.shape[1]) if self.positional_embedding is not None else None
         token_emb = self.embedding_layer(text_tokens, pos=pos)  # lookup + positional add in one kernel
         return self.embedding_dropout(token_emb)
 

@@ -380,9 +380,9 @@ class LearnablePositionalEmbedding(nn.Module):
             with torch.no_grad():
                 self.pos_embed[:, :, self.padding_idx, ...] = 0.0
 
-    def forward(self, seq_len: int, *args, **kwargs) -> Tensor:
-        """returns the [seq_len, E] float32 table (bilinearly resized along the sequence axis when seq_len differs,
-        positional_embedding.py:90-95); the batch broadcast happens inside the embedding kernel."""
+    def table(self, seq_len: int) -> Tensor:
+        """the [seq_len, E] float32 table (bilinearly resized along the sequence axis when seq_len differs, positional_embedding.py:90-95);
+        the embedding kernels broadcast it over the batch themselves."""
         if self.interpolation_mode != "bilinear":
             raise NotImplementedError("non-bilinear positional embeddings are not on the HIP hot path")
         if self.padding_idx is not None:  # positional_embedding.py:84-86: the padding position is re-zeroed on every call
@@ -394,6 +394,11 @@ class LearnablePositionalEmbedding(nn.Module):
             fm = pe.view(1, self.num_embeddings, 1, self.embedding_dim).permute(0, 3, 1, 2)
             pe = ops.resize_bilinear(fm, seq_len, 1).permute(0, 2, 3, 1).reshape(seq_len, self.embedding_dim)
         return pe
+
+    def forward(self, seq_len: int, *args, **kwargs) -> Tensor:
+        """reference contract (positional_embedding.py:81-104): [seq_len, 1, E] when sequence_first else [1, seq_len, E]"""
+        pe = self.table(seq_len)
+        return pe.reshape(seq_len, 1, self.embedding_dim) if self.sequence_first else pe.reshape(1, seq_len, self.embedding_dim)
 
     def __repr__(self):
         return "{}(num_embeddings={}, embedding_dim={}, padding_idx={}, sequence_first={})".format(
@@ -408,6 +413,9 @@ class PositionalEmbedding(nn.Module):
             raise NotImplementedError("sinusoidal positional embeddings are not on the HIP hot path")
         self.pos_embed = LearnablePositionalEmbedding(opts, num_embeddings=num_embeddings, embedding_dim=embedding_dim, padding_idx=padding_idx,
                                                       sequence_first=sequence_first, interpolation_mode=interpolation_mode)
+
+    def table(self, seq_len: int) -> Tensor:
+        return self.pos_embed.table(seq_len)
 
     def forward(self, seq_len: int, *args, **kwargs) -> Tensor:
         return self.pos_embed(seq_len, *args, **kwargs)

@@ -212,7 +212,7 @@ class VisionTransformer(nn.Module):
         fm = self.patch_emb(ops.to_nhwc(x))
         B, E, n_h, n_w = fm.shape
         N = n_h * n_w
-        pos = self.pos_embed(N)
+        pos = self.pos_embed.table(N)
         cls = self.cls_token.view(E) if self.cls_token is not None else None
         t = ops.VitEmbed.apply(ops.tokens_of(fm), pos, cls, B)
         t = ops.dropout(t, self.emb_dropout.p, self.training)

@@ -832,7 +832,7 @@ class AttentionFn(torch.autograd.Function):
 def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None):
     kpm = None
     if key_padding_mask is not None:
-        kpm = key_padding_mask.to(torch.uint8).contiguous()  # plumbing
+        kpm = (key_padding_mask != 0).to(torch.uint8).contiguous()  # plumbing; any non-zero entry (True, 1, -inf) masks the key, as .to(torch.bool) does in the reference
     return AttentionFn.apply(qkv2d, kpm, (int(heads), tuple(int(v) for v in seqmap), bool(causal)))
 
 

@@ -206,3 +206,43 @@ def test_patch_conv_dx_and_dw(dtype, cfg):
     assert l2_err(xg.grad.float().cpu(), xr.grad) < tol
     assert l2_err(layer.block.conv.weight.grad.float().cpu(), wr.grad) < tol
     assert l2_err(layer.block.conv.bias.grad.float().cpu(), br.grad) < tol
+
+
+def test_masked_attention_like_reference_test():
+    """mirror of the reference's tests/modules/test_transformer.py::test_masked_attention (float -inf key padding mask, 8 heads of
+    dimension 1, 66 tokens): unmasked queries of a masked sequence agree with each other, masked positions differ, the unmasked
+    sequence is uniform."""
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    B, N, C = 2, 64 + 2, 8
+    t = cvnets_amd.TransformerEncoder(default_opts(), embed_dim=C, ffn_latent_dim=4 * C).cuda().eval()
+    x = torch.ones([B, N, C])
+    x[:, :] = torch.randn([C])
+    key_padding_mask = torch.zeros([B, N])
+    key_padding_mask[0, 63:] = float("-inf")
+    x[0, 63:] = 0
+    y = t(x.cuda(), key_padding_mask=key_padding_mask.cuda()).float().cpu()
+    assert torch.all((y[0, 0] - y[0, :63]).abs() < 1e-5)
+    assert torch.all(y[0, 0] != y[0, 63:])
+    assert torch.all((y[1, 0] - y[1, :]).abs() < 1e-5)
+
+
+@pytest.mark.parametrize("input_seq_len", [34, 128, 192])
+@pytest.mark.parametrize("sequence_first", [True, False])
+@pytest.mark.parametrize("padding_idx", [None, 0])
+def test_pos_embedding_like_reference_test(input_seq_len, sequence_first, padding_idx):
+    """mirror of the reference's tests/test_pos_embeddings.py (learnable variant): output shape contract, plus values vs F.interpolate"""
+    from cvnets_amd.layers import PositionalEmbedding
+
+    pe = PositionalEmbedding(opts=None, num_embeddings=128, embedding_dim=512, padding_idx=padding_idx, is_learnable=True,
+                             sequence_first=sequence_first).cuda()
+    out = pe(input_seq_len)
+    assert out.shape[0 if sequence_first else 1] == input_seq_len and out.shape[1 if sequence_first else 0] == 1
+    w = pe.pos_embed.pos_embed.detach().cpu()
+    ref = F.interpolate(w, size=(input_seq_len, 512), mode="bilinear") if input_seq_len != 128 else w
+    assert l2_err(out.float().cpu().reshape(input_seq_len, 512), ref.reshape(input_seq_len, 512)) < 1e-6
+    if padding_idx is not None:
+        assert float(pe.pos_embed.pos_embed[0, 0, padding_idx].abs().max()) == 0.0

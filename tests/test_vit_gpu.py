@@ -246,3 +246,28 @@ def test_pos_embedding_like_reference_test(input_seq_len, sequence_first, paddin
     assert l2_err(out.float().cpu().reshape(input_seq_len, 512), ref.reshape(input_seq_len, 512)) < 1e-6
     if padding_idx is not None:
         assert float(pe.pos_embed.pos_embed[0, 0, padding_idx].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("output_dim", [32, 48])
+@pytest.mark.parametrize("batch_size", [1, 2])
+@pytest.mark.parametrize("bias", [True, False])
+@pytest.mark.parametrize("use_attn_mask", [True, False])
+def test_multihead_self_attn_like_reference_test(output_dim, batch_size, bias, use_attn_mask):
+    """mirror of the reference's tests/test_multi_head_attn.py::test_multihead_self_attn (seq 5, embed 8, 2 heads, output_dim != embed_dim,
+    with / without bias, with / without the causal additive mask): the HIP layer vs the oracle's forward_default restatement, which
+    oracle/make_golden.py pins against the reference (whose own test pins forward_default against torch's MHA)."""
+    import cvnets_amd
+    from oracle import mobilevit_oracle as orc
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    seq_len, embed_dim = 5, 8
+    mha = cvnets_amd.MultiHeadAttention(embed_dim=embed_dim, num_heads=2, attn_dropout=0.0, bias=bias, output_dim=output_dim).cuda().eval()
+    x = torch.randn(batch_size, seq_len, embed_dim)
+    mask = None
+    if use_attn_mask:
+        mask = torch.full((seq_len, seq_len), float("-inf")).triu_(1).unsqueeze(0).expand(batch_size, -1, -1)
+    got = mha(x_q=x.cuda(), attn_mask=mask.cuda() if mask is not None else None).float().cpu()
+    sd = {"mha." + k: v.detach().cpu() for k, v in mha.state_dict().items()}
+    ref = orc.multi_head_attention(sd, "mha", x, 2, attn_mask=mask)
+    torch.testing.assert_close(actual=got, expected=ref, atol=1e-4, rtol=1e-4)

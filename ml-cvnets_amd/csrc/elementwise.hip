@@ -94,7 +94,11 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, T* __restrict__ 
 // (7 x int64 per entry, entries sorted by first element; table[n][6] = total).  Same three layouts as above.
 template <typename T>
 __global__ void weight_pack_multi_kernel(const long long* __restrict__ table, int n, long long total, T* __restrict__ out) {
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+  // thread = 8 consecutive packed elements = one 16-byte (bf16) store.  Every tensor's packed size and row length are multiples
+  // of 8, so a chunk never straddles tensors or rows: the 8 sources are one base address + a constant stride.
+  const long long total8 = total / 8;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total8; q += (long long)gridDim.x * blockDim.x) {
+    const long long idx = q * 8;
     int lo = 0, hi = n - 1;
     while (lo < hi) {  // last entry whose first element <= idx
       const int mid = (lo + hi + 1) >> 1;
@@ -102,30 +106,32 @@ __global__ void weight_pack_multi_kernel(const long long* __restrict__ table, in
     }
     const long long* e = table + (size_t)lo * 7;
     const float* w = reinterpret_cast<const float*>(e[0]);
-    const long long li = idx - e[6];
-    const int Cout = (int)e[2], Cin = (int)e[3], KHW = (int)e[4], mode = (int)e[5];
-    const int Cp = (Cin + 7) / 8 * 8, Np = (Cout + 7) / 8 * 8;
-    float v = 0.f;
-    if (mode == 0) {
-      const int c = (int)(li % Cp);
-      const long long t = li / Cp;
-      const int tap = (int)(t % KHW), nn = (int)(t / KHW);
-      if (c < Cin) v = w[((size_t)nn * Cin + c) * KHW + tap];
-    } else if (mode == 1) {
-      const int nn = (int)(li % Np);
-      const long long t = li / Np;
-      const int tap = (int)(t % KHW), c = (int)(t / KHW);
-      if (nn < Cout) v = w[((size_t)nn * Cin + c) * KHW + (KHW - 1 - tap)];
-    } else if (mode == 3) {
-      const int nn = (int)(li % Np);
-      const long long t = li / Np;
-      const int c = (int)(t % Cp), tap = (int)(t / Cp);
-      if (nn < Cout && c < Cin) v = w[((size_t)nn * Cin + c) * KHW + tap];
-    } else {
-      const int c = (int)(li % Cout), tap = (int)(li / Cout);
-      v = w[(size_t)c * KHW + tap];
+    const unsigned li = (unsigned)(idx - e[6]);  // position inside this tensor's packed image (< 2^32)
+    const unsigned Cout = (unsigned)e[2], Cin = (unsigned)e[3], KHW = (unsigned)e[4];
+    const int mode = (int)e[5];
+    const unsigned Cp = (Cin + 7) / 8 * 8, Np = (Cout + 7) / 8 * 8;
+    size_t base;       // source index of element 0 of the chunk
+    unsigned stride;   // source distance between consecutive packed elements
+    unsigned first, limit;  // elements j with first + j >= limit are padding (zero)
+    if (mode == 0) {   // [Cout][KHW][Cp]
+      const unsigned c = li % Cp, t = li / Cp, tap = t % KHW, nn = t / KHW;
+      base = ((size_t)nn * Cin + c) * KHW + tap; stride = KHW; first = c; limit = Cin;
+    } else if (mode == 1) {  // [Cin][KHW flipped][Np]
+      const unsigned nn = li % Np, t = li / Np, tap = t % KHW, c = t / KHW;
+      base = ((size_t)nn * Cin + c) * KHW + (KHW - 1 - tap); stride = Cin * KHW; first = nn; limit = Cout;
+    } else if (mode == 3) {  // [KHW][Cp][Np]
+      const unsigned nn = li % Np, t = li / Np, c = t % Cp, tap = t / Cp;
+      base = ((size_t)nn * Cin + c) * KHW + tap; stride = Cin * KHW; first = nn; limit = c < Cin ? Cout : 0;
+    } else {  // depthwise [KHW][C]
+      const unsigned c = li % Cout, tap = li / Cout;
+      base = (size_t)c * KHW + tap; stride = KHW; first = c; limit = Cout;
     }
-    out[e[1] + li] = from_f<T>(v);
+    float v[8];
+#pragma unroll
+    for (unsigned jj = 0; jj < 8; ++jj) v[jj] = (first + jj < limit) ? w[base + (size_t)jj * stride] : 0.f;
+    V8<T> o;
+    v8_pack(v, o);
+    v8_store<T>(out + e[1] + li, o);
   }
 }
 
@@ -634,7 +640,7 @@ extern "C" int cvh_weight_pack(int dtype, const float* w, void* out, int Cout, i
 }
 extern "C" int cvh_weight_pack_multi(int dtype, const long long* table, int n_entries, long long total, void* out, void* stream) {
   if (n_entries <= 0 || total <= 0) return 0;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((weight_pack_multi_kernel<T>), dim3(grid_for((size_t)total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, table, n_entries, total, (T*)out);)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((weight_pack_multi_kernel<T>), dim3(grid_for((size_t)total / 8, 256, 2048)), dim3(256), 0, (hipStream_t)stream, table, n_entries, total, (T*)out);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

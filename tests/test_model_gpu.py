@@ -121,6 +121,29 @@ def test_train_step_vs_live_oracle(dtype):
         assert l2_err(sd_after[k].float().cpu(), v) < (1e-4 if fp32 else 3e-2), k
 
 
+def test_x_small_vs_live_oracle():
+    """the third MobileViT size (x_small: expansion 4, 32..96 channels, transformer dims 96/120/144 -> head dims 24/30/36)"""
+    from oracle import mobilevit_oracle as orc
+    from oracle.weights import seeded_input, seeded_labels, seeded_state_dict
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+
+    opts = default_opts(**{"model.classification.mit.mode": "x_small", "model.classification.mit.dropout": 0.0,
+                           "model.classification.classifier_dropout": 0.0})
+    model = cvnets_amd.MobileViT(opts)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
+    model.load_state_dict(sd)
+    cvnets_amd.set_compute_dtype(torch.float32)
+    model = model.cuda()
+    x, y = seeded_input((2, 3, 96, 96), seed=9), seeded_labels(2, 1000, seed=9)
+    logits, loss, grads = _step(model, x.cuda(), y.cuda())
+    o_logits, o_loss, o_grads, _ = orc.train_step(sd, x, y, mode="x_small")
+    assert l2_err(logits, o_logits) < 1e-4 and abs(loss - float(o_loss)) < 1e-4
+    gmax = max(float(v.norm()) for v in o_grads.values())
+    for k, g in o_grads.items():
+        assert l2_err(grads[k], g) < 2e-3 or g.norm() < 1e-5 * gmax, (k, l2_err(grads[k], g))
+
+
 def test_rectangular_and_batch1():
     """edge cases: batch 1, non-square input, eval mode (running statistics)."""
     from oracle import mobilevit_oracle as orc

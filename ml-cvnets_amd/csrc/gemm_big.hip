@@ -144,6 +144,12 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], p.act);
       }
+      if (p.actgrad_aux) {  // backward through the producer's activation: v *= act'(pre-activation of the layer below)
+        float a[8];
+        v8_unpack(v8_load<bf16_t>(reinterpret_cast<const bf16_t*>(p.actgrad_aux) + o), a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= act_grad(a[j], p.actgrad_act);
+      }
       if (p.drop_p > 0.f) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(seed, p.stream_id, o + j, p.drop_p, inv_keep);
@@ -165,7 +171,7 @@ bool gemm_big_eligible(const ConvGemmParams& p) {
   if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
   const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
   return linear && p.M >= 2048 && p.N >= 256 && (p.N % BN) == 0 && p.Ktot >= 256 && (p.Ktot % BK) == 0 && p.stats_part == nullptr &&
-         p.actgrad_aux == nullptr && p.sc_s == 0;
+         p.sc_s == 0;
 }
 
 int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {

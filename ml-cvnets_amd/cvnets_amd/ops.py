@@ -653,11 +653,15 @@ class BatchNormAct(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class LinearAct(torch.autograd.Function):
     """LinearLayer.forward = F.linear (cvnets/layers/linear_layer.py:74-91) with the activation / Dropout / residual
-    add that follow it in TransformerEncoder (cvnets/modules/transformer.py:140-155) fused into the GEMM epilogue."""
+    add that follow it in TransformerEncoder (cvnets/modules/transformer.py:140-155) fused into the GEMM epilogue.
+
+    FFN pairing (fc1 -> act -> fc2): with ``expose_pre`` fc1 also returns its pre-activation tensor; fc2 takes it as ``in_pre`` and
+    its dX GEMM multiplies by act'(pre) in the epilogue, handing fc1 the gradient of the PRE-activation directly — the separate
+    activation-backward pass over the 4x-wide hidden tensor (2 reads + 1 write) disappears."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, cfg):
-        act, drop_p, stream_id = cfg
+    def forward(ctx, x, weight, bias, residual, in_pre, cfg):
+        act, drop_p, stream_id, expose_pre, in_act = cfg
         _check_dev(x)
         rows, K = x.shape
         N = weight.shape[0]
@@ -674,37 +678,52 @@ class LinearAct(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
         ctx.bias = bias
-        ctx.save_for_backward(x, weight, pre)
+        ctx.save_for_backward(x, weight, pre, in_pre)
+        if expose_pre:
+            if pre is None:
+                raise RuntimeError("expose_pre needs an activation")
+            ctx.set_materialize_grads(False)
+            return out, pre
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        act, drop_p, stream_id = ctx.cfg
-        x, weight, pre = ctx.saved_tensors
+    def backward(ctx, dout, dpre=None):
+        act, drop_p, stream_id, expose_pre, in_act = ctx.cfg
+        x, weight, pre, in_pre = ctx.saved_tensors
         rows, K = x.shape
         N = weight.shape[0]
-        dev, dtype = dout.device, dout.dtype
-        dout = dout.contiguous()
-        dy = dout
-        if drop_p > 0:
-            dy = torch.empty_like(dout)
-            _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(dropout_seed(dev)), stream_id, _stream())
-        if act != ACT_NONE:
-            dy = _act_backward(pre, dy, act, rows, N)
+        if expose_pre and dout is None:
+            dy = dpre.contiguous()  # already the gradient of the pre-activation (fused into the consumer's dX GEMM)
+            dev, dtype = dy.device, dy.dtype
+        else:
+            dev, dtype = dout.device, dout.dtype
+            dout = dout.contiguous()
+            dy = dout
+            if drop_p > 0:
+                dy = torch.empty_like(dout)
+                _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(dropout_seed(dev)), stream_id, _stream())
+            if act != ACT_NONE:
+                dy = _act_backward(pre, dy, act, rows, N)
+            if expose_pre and dpre is not None:
+                dy = add(dy, dpre.contiguous())
         dbias = _colsum(dy, rows, N, _grad_sink(ctx.bias)) if ctx.has_bias else None
         dw_ret = _weight_grad(dy, x, None, K, 0, weight, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K)
-        dx = None
-        if ctx.needs_input_grad[0]:
+        dx = d_in_pre = None
+        if ctx.needs_input_grad[0] or (in_pre is not None and ctx.needs_input_grad[4]):
             wpt = pack_weight(weight, dtype, 1)  # [K][N]
             dx = torch.empty((rows, K), dtype=dtype, device=dev)
-            _conv_gemm(dy, None, N, 0, wpt, dx, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, K)
-        dres = dout if ctx.has_res else None
-        return dx, dw_ret, dbias, dres, None
+            if in_pre is not None:  # x = act(in_pre): hand the producer d(in_pre) = (dy W) * act'(in_pre)
+                _conv_gemm(dy, None, N, 0, wpt, dx, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, K, actgrad_aux=in_pre, actgrad_act=in_act)
+                d_in_pre, dx = dx, None
+            else:
+                _conv_gemm(dy, None, N, 0, wpt, dx, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, K)
+        dres = dout if (ctx.has_res and dout is not None) else None
+        return dx, dw_ret, dbias, dres, d_in_pre, None
 
 
-def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None):
+def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None, expose_pre=False, in_pre=None, in_act=ACT_NONE):
     sid = next_stream_id() if drop_p > 0 else 0
-    return LinearAct.apply(x2d, weight, bias, residual, (int(act), float(drop_p), sid))
+    return LinearAct.apply(x2d, weight, bias, residual, in_pre, (int(act), float(drop_p), sid, bool(expose_pre), int(in_act)))
 
 
 # ------------------------------------------------------------------------------------------------

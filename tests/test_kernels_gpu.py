@@ -369,7 +369,7 @@ def test_big_gemm_matches_generic_kernel(ops):
     for knob in (1, 0, 2):
         _lib.call("cvh_set_tuning", 5, knob)
         try:
-            y = ops.LinearAct.apply(x, w, b, res, (2, 0.1, 77))
+            y = ops.LinearAct.apply(x, w, b, res, None, (2, 0.1, 77, False, 0))
             outs.append(y.float())
         finally:
             _lib.call("cvh_set_tuning", 5, 1)
@@ -451,3 +451,26 @@ def test_layer_norm_reference_quirk(ops, dtype, cfg):
     ln.reference_quirk = False  # opt-out: the documented channel-last LayerNorm
     y2 = ops.layer_norm_tokens(x, ln, seqmap)
     check("ln no-quirk", y2, F.layer_norm(x.detach().float(), (C,), ln.weight.detach(), ln.bias.detach(), ln.eps), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,H", [(300, 64, 128), (2500, 256, 1024)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_ffn_pair_fused_activation_backward(ops, dtype, M, K, H, act):
+    """fc1 -> act -> fc2 with the activation backward folded into fc2's dX GEMM epilogue (LinearAct expose_pre / in_pre) must give the
+    same outputs and gradients as the unfused pair (second shape: the large-tile kernel in bf16)."""
+    x = _rand(M, K, seed=21).to(dtype).requires_grad_(True)
+    w1 = _rand(H, K, seed=22, scale=1 / math.sqrt(K)).requires_grad_(True)
+    b1 = _rand(H, seed=23, scale=0.1).requires_grad_(True)
+    w2 = _rand(K, H, seed=24, scale=1 / math.sqrt(H)).requires_grad_(True)
+    b2 = _rand(K, seed=25, scale=0.1).requires_grad_(True)
+    go = _rand(M, K, seed=26).to(dtype)
+    h, pre = ops.linear(x, w1, b1, act=act, expose_pre=True)
+    y = ops.linear(h, w2, b2, residual=x, in_pre=pre, in_act=act)
+    g_f = torch.autograd.grad(y, [x, w1, b1, w2, b2], go)
+    h0 = ops.linear(x, w1, b1, act=act)
+    y0 = ops.linear(h0, w2, b2, residual=x)
+    g_u = torch.autograd.grad(y0, [x, w1, b1, w2, b2], go)
+    assert torch.equal(y, y0)
+    for name, a, b in zip(("dx", "dw1", "db1", "dw2", "db2"), g_f, g_u):
+        check(f"ffn fused {name}", a, b, dtype, scale=1 if dtype == torch.float32 else 2)

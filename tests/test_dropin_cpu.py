@@ -185,3 +185,29 @@ def test_clip_class_swap(ref_model):
     assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in model.state_dict().items()}
     with pytest.raises(RuntimeError):
         model({"image": torch.zeros(2, 3, 64, 64), "text": torch.ones(2, 77, dtype=torch.long)})
+
+
+def test_vbs_shape_schedule_matches_reference():
+    """cvnets_amd.schedule vs the reference's data/sampler/utils.py (loaded as a plain module: the `data` package itself needs
+    torchvision) for the two shipped recipes, and the per-step draw vs random.seed(epoch) + random.choice."""
+    import importlib.util
+    import random
+
+    from cvnets_amd import schedule
+
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("ref_sampler_utils", os.path.join(REF, "data", "sampler", "utils.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    for args in (dict(crop_size_w=256, crop_size_h=256, batch_size_gpu0=128, max_scales=5, check_scale_div_factor=32, min_crop_size_w=160,
+                      max_crop_size_w=320, min_crop_size_h=160, max_crop_size_h=320),      # mobilevit.yaml
+                 dict(crop_size_w=384, crop_size_h=384, batch_size_gpu0=128, max_scales=5, check_scale_div_factor=32, min_crop_size_w=256,
+                      max_crop_size_w=512, min_crop_size_h=256, max_crop_size_h=512),      # BASELINE config 5
+                 dict(crop_size_w=224, crop_size_h=224, batch_size_gpu0=64, max_scales=7, check_scale_div_factor=16, min_crop_size_w=128,
+                      max_crop_size_w=320, min_crop_size_h=128, max_crop_size_h=320)):
+        assert schedule.image_batch_pairs(**args) == ref.image_batch_pairs(**args), args
+    pairs = schedule.image_batch_pairs(384, 384, 128, 5, 32, 256, 512, 256, 512)
+    assert pairs == [(256, 256, 288), (320, 320, 184), (384, 384, 128), (448, 448, 94), (512, 512, 72)]
+    random.seed(3)
+    expect = [random.choice(pairs) for _ in range(25)]
+    assert schedule.vbs_sequence(pairs, 25, epoch=3) == expect

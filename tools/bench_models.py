@@ -131,7 +131,9 @@ def run_vbs(steps, warmup, dtype):
     import cvnets_amd
     from cvnets_amd.ddp import DistributedDataParallel
 
-    pairs = [(256, 288), (320, 184), (384, 128), (448, 94), (512, 72)]
+    from cvnets_amd.schedule import image_batch_pairs, vbs_sequence
+
+    pairs = [(h, b) for h, w, b in image_batch_pairs(384, 384, 128, 5, 32, 256, 512, 256, 512)]  # [(256, 288), (320, 184), (384, 128), (448, 94), (512, 72)]
     dev = torch.device("cuda", 0)
     cvnets_amd.set_compute_dtype(dtype)
     torch.manual_seed(1234)
@@ -159,8 +161,7 @@ def run_vbs(steps, warmup, dtype):
         opt.step()  # builds the optimizer tables (eager, tiny batch)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    rng = random.Random(0)
-    seq = [rng.choice(pairs) for _ in range(warmup + steps)]
+    seq = vbs_sequence(pairs, warmup + steps, epoch=0)
 
     def step(hw):
         if hw not in graphs:

@@ -1193,16 +1193,17 @@ class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, stream_id):
         _check_dev(x)
-        x = x.contiguous()
-        y = torch.empty_like(x)
+        if not (x.is_contiguous() or is_nhwc(x)):
+            x = x.contiguous()
+        y = torch.empty_like(x)  # same (dense) layout as x: the mask is a function of the MEMORY index, NHWC maps stay NHWC
         _lib.call("cvh_dropout", _dt(x), _p(x), _p(y), x.numel(), float(p), _p(dropout_seed(x.device)), stream_id, _stream())
-        ctx.cfg = (p, stream_id)
+        ctx.cfg = (p, stream_id, is_nhwc(x) and not x.is_contiguous())
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        p, stream_id = ctx.cfg
-        dy = dy.contiguous()
+        p, stream_id, nhwc = ctx.cfg
+        dy = as_nhwc(dy) if nhwc else dy.contiguous()  # the gradient must be walked in the layout the forward mask was drawn in
         dx = torch.empty_like(dy)
         _lib.call("cvh_dropout", _dt(dy), _p(dy), _p(dx), dy.numel(), float(p), _p(dropout_seed(dy.device)), stream_id, _stream())
         return dx, None, None

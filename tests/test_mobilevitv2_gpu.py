@@ -230,3 +230,30 @@ def test_resize_bilinear_align_corners(dtype, cfg):
     tol = 1e-5 if dtype == torch.float32 else 8e-3
     assert l2_err(y.float().cpu(), yr.detach()) < tol
     assert l2_err(xg.grad.float().cpu(), xr.grad) < tol
+
+
+def test_v2_with_dropout_trains_and_is_layout_consistent():
+    """mitv2.dropout / ffn_dropout > 0 (not the shipped default): the un-fused dropout + residual-add path on NHWC maps runs forward and
+    backward, masks are regenerated consistently in backward (kept positions of dX == kept positions of Y), eval is deterministic."""
+    import cvnets_amd
+    from cvnets_amd import ops
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    x = ops.to_nhwc(torch.randn(2, 16, 6, 8).cuda()).detach().requires_grad_()
+    y = ops.dropout(x, 0.5, True)
+    assert y.stride() == x.stride()
+    kept = y != 0
+    assert 0.3 < float(kept.float().mean()) < 0.7
+    assert torch.allclose(y[kept], 2.0 * x.detach()[kept])
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, kept)
+    model = cvnets_amd.build_mobilevit_v2(0.5, **{"model.classification.mitv2.dropout": 0.1, "model.classification.mitv2.ffn_dropout": 0.1}).cuda()
+    inp = torch.randn(2, 3, 64, 64).cuda()
+    model.train()
+    out = model(inp)
+    out.float().square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(inp), model(inp))

@@ -257,3 +257,31 @@ def test_v2_with_dropout_trains_and_is_layout_consistent():
     model.eval()
     with torch.no_grad():
         assert torch.equal(model(inp), model(inp))
+
+
+@pytest.mark.parametrize("wm,batch,hw", [(2.0, 2, (64, 64)), (1.5, 1, (96, 64))])
+def test_v2_other_widths_vs_live_oracle(wm, batch, hw):
+    """width 2.0 is what config/classification/imagenet/mobilevit_v2.yaml ships (attention dims 256 / 384 / 512: the 64-lane-per-row
+    variant of the linear-attention kernels); 1.5 with batch 1 on a rectangular input covers the odd sizes in between."""
+    import cvnets_amd
+    from oracle import mobilevit_oracle as orc
+    from oracle.weights import seeded_input, seeded_labels, seeded_state_dict
+
+    model = cvnets_amd.build_mobilevit_v2(wm)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0)
+    model.load_state_dict(sd)
+    cvnets_amd.set_compute_dtype(torch.float32)
+    model = model.cuda()
+    x, y = seeded_input((batch, 3) + hw, seed=5), seeded_labels(batch, 1000, seed=5)
+    if batch == 1:  # train-mode BatchNorm over a 2x2 map of one image is degenerate: compare the eval forward only
+        model.eval()
+        with torch.no_grad():
+            got = model(x.cuda()).float().cpu()
+        assert l2_err(got, orc.mobilevit_v2_forward(sd, x, width_multiplier=wm, training=False)) < 1e-4
+        return
+    logits, loss, grads = _step(model, x.cuda(), y.cuda())
+    o_logits, o_loss, o_grads, _ = orc.generic_train_step(orc.mobilevit_v2_forward, sd, x, y, width_multiplier=wm)
+    assert l2_err(logits, o_logits) < 1e-4 and abs(loss - float(o_loss)) < 1e-4
+    gmax = max(float(v.norm()) for v in o_grads.values())
+    for k, g in o_grads.items():
+        assert l2_err(grads[k], g) < 2e-3 or g.norm() < 1e-4 * gmax, (k, l2_err(grads[k], g))

@@ -207,3 +207,25 @@ def test_inplace_param_grads_and_pack_plan_match_autograd_path():
                 assert abs(float(loss) - loss_ref) > 1e-3
     finally:
         ops.set_inplace_param_grads(False)
+
+
+def test_mobilevit_option_variants_vs_live_oracle_structure():
+    """constructor options of the reference that change the graph: no_fuse_local_global_features (block returns conv_proj output) and
+    head_dim instead of number_heads; both must build, run forward + backward and keep the reference's parameter names."""
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    x = torch.randn(2, 3, 64, 64).cuda()
+    for extra in ({"model.classification.mit.no_fuse_local_global_features": True},
+                  {"model.classification.mit.head_dim": 16, "model.classification.mit.number_heads": None}):
+        opts = default_opts(**{"model.classification.mit.mode": "xx_small", **extra})
+        model = cvnets_amd.MobileViT(opts).cuda().train()
+        out = model(x)
+        assert out.shape == (2, 1000)
+        out.float().square().mean().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        if "model.classification.mit.no_fuse_local_global_features" in extra:
+            assert not any("fusion" in k for k in model.state_dict())
+        else:
+            assert model.layer_3[1].global_rep[0].pre_norm_mha[1].num_heads == 64 // 16

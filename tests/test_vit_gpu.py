@@ -271,3 +271,27 @@ def test_multihead_self_attn_like_reference_test(output_dim, batch_size, bias, u
     sd = {"mha." + k: v.detach().cpu() for k, v in mha.state_dict().items()}
     ref = orc.multi_head_attention(sd, "mha", x, 2, attn_mask=mask)
     torch.testing.assert_close(actual=got, expected=ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["small", "base"])
+def test_vit_other_sizes_vs_live_oracle(mode):
+    """ViT small (384 / 6 heads) and base (768 / 12 heads; bf16 linears of this size take the large-tile kernels) at 64x64, batch 2."""
+    import cvnets_amd
+    from oracle import mobilevit_oracle as orc
+    from oracle.weights import seeded_input, seeded_labels, seeded_state_dict
+
+    model = cvnets_amd.build_vit(mode, **{"model.classification.vit.dropout": 0.0})
+    model.emb_dropout.p = 0.0
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    sd["cls_token"] = 0.02 * seeded_state_dict({"cls_token_values": shapes["cls_token"]}, seed=0)["cls_token_values"]
+    model.load_state_dict(sd)
+    cvnets_amd.set_compute_dtype(torch.float32)
+    model = model.cuda()
+    x, y = seeded_input((2, 3, 64, 64), seed=6), seeded_labels(2, 1000, seed=6)
+    logits, loss, grads = _step(model, x.cuda(), y.cuda())
+    o_logits, o_loss, o_grads, _ = orc.generic_train_step(orc.vit_forward, sd, x, y, mode=mode)
+    assert l2_err(logits, o_logits) < 1e-4 and abs(loss - float(o_loss)) < 1e-4
+    gmax = max(float(v.norm()) for v in o_grads.values())
+    for k, g in o_grads.items():
+        assert l2_err(grads[k], g) < 2e-3 or g.norm() < 1e-5 * gmax, (k, l2_err(grads[k], g))

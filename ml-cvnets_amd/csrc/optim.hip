@@ -5,7 +5,8 @@
 // group and the step counter are DEVICE values, so the launch can sit inside a captured hipGraph while a scheduler changes the rate.
 //
 // table[n+1][8] (int64): param ptr, grad ptr, ema ptr (0 = none), state offset, numel, group index, prefix start, unused;
-// row n carries only the total in its prefix field.  Thread = 4 consecutive elements of the concatenated index space.
+// row n carries only the total in its prefix field.  Thread = 4 consecutive elements of the concatenated index space; every tensor
+// starts at a multiple of 4 in that space (and in the moment buffers), so a thread's elements belong to one tensor and move as float4.
 #include "common.hpp"
 #include "cvnets_hip.h"
 
@@ -27,30 +28,45 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const long long* __res
       const int mid = (lo + hi + 1) >> 1;
       if (table[(size_t)mid * 8 + 6] <= e0) lo = mid; else hi = mid - 1;
     }
-    int ti = lo;
+    const long long* row = table + (size_t)lo * 8;
+    const long long k0 = e0 - row[6];  // multiple of 4: the host pads every tensor's start to 4 elements
+    const long long numel = row[4];
+    if (k0 >= numel) continue;         // padding between tensors
+    float* p = reinterpret_cast<float*>(row[0]);
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    float* ema = reinterpret_cast<float*>(row[2]);
+    const long long so = row[3] + k0;
+    const float lr = group_hp[row[5] * 2], wd = group_hp[row[5] * 2 + 1];
+    const float decay = 1.0f - lr * wd, step_size = lr / bc1;
+    float w[4], gr[4], m[4], v[4], ev[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = k0 + 3 < numel && ((reinterpret_cast<uintptr_t>(p + k0) | reinterpret_cast<uintptr_t>(g + k0)) & 15) == 0 &&
+                     (ema == nullptr || (reinterpret_cast<uintptr_t>(ema + k0) & 15) == 0);
+    const int cnt = vec ? 4 : (int)((numel - k0) < 4 ? (numel - k0) : 4);
+    if (vec) {
+      const float4 a = *reinterpret_cast<const float4*>(p + k0), b = *reinterpret_cast<const float4*>(g + k0);
+      const float4 c = *reinterpret_cast<const float4*>(m_flat + so), d = *reinterpret_cast<const float4*>(v_flat + so);
+      w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;  gr[0] = b.x; gr[1] = b.y; gr[2] = b.z; gr[3] = b.w;
+      m[0] = c.x; m[1] = c.y; m[2] = c.z; m[3] = c.w;  v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w;
+      if (ema) { const float4 q = *reinterpret_cast<const float4*>(ema + k0); ev[0] = q.x; ev[1] = q.y; ev[2] = q.z; ev[3] = q.w; }
+    } else {
+      for (int j = 0; j < cnt; ++j) { w[j] = p[k0 + j]; gr[j] = g[k0 + j]; m[j] = m_flat[so + j]; v[j] = v_flat[so + j]; if (ema) ev[j] = ema[k0 + j]; }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long long e = e0 + j;
-      if (e >= total) break;
-      while (e >= table[(size_t)(ti + 1) * 8 + 6]) ++ti;  // crossed into the next tensor
-      const long long* row = table + (size_t)ti * 8;
-      const long long k = e - row[6];
-      float* p = reinterpret_cast<float*>(row[0]);
-      const float* g = reinterpret_cast<const float*>(row[1]);
-      float* ema = reinterpret_cast<float*>(row[2]);
-      const long long so = row[3] + k;
-      const float lr = group_hp[row[5] * 2], wd = group_hp[row[5] * 2 + 1];
-      const float grad = g[k] * gs;
-      float w = p[k] * (1.0f - lr * wd);
-      float m = m_flat[so];
-      m = m + (grad - m) * (1.0f - beta1);
-      const float v = v_flat[so] * beta2 + grad * grad * (1.0f - beta2);
-      const float denom = sqrtf(v) / sbc2 + eps;
-      w -= (lr / bc1) * (m / denom);
-      p[k] = w;
-      m_flat[so] = m;
-      v_flat[so] = v;
-      if (ema) ema[k] = ema[k] * (1.0f - ema_momentum) + ema_momentum * w;
+      const float grad = gr[j] * gs;
+      w[j] *= decay;
+      m[j] = m[j] + (grad - m[j]) * (1.0f - beta1);
+      v[j] = v[j] * beta2 + grad * grad * (1.0f - beta2);
+      w[j] -= step_size * (m[j] / (sqrtf(v[j]) / sbc2 + eps));
+      ev[j] = ev[j] * (1.0f - ema_momentum) + ema_momentum * w[j];
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(p + k0) = make_float4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<float4*>(m_flat + so) = make_float4(m[0], m[1], m[2], m[3]);
+      *reinterpret_cast<float4*>(v_flat + so) = make_float4(v[0], v[1], v[2], v[3]);
+      if (ema) *reinterpret_cast<float4*>(ema + k0) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    } else {
+      for (int j = 0; j < cnt; ++j) { p[k0 + j] = w[j]; m_flat[so + j] = m[j]; v_flat[so + j] = v[j]; if (ema) ema[k0 + j] = ev[j]; }
     }
   }
 }

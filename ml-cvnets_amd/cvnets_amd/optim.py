@@ -53,7 +53,7 @@ class AdamW(torch.optim.Optimizer):
                 p.grad = torch.zeros_like(p)
             e = ema_by_id.get(id(p))
             rows.append([p.data_ptr(), p.grad.data_ptr(), e.data_ptr() if e is not None else 0, off, p.numel(), gi, off, 0])
-            off += p.numel()
+            off += (p.numel() + 3) // 4 * 4  # every tensor starts on a 4-element boundary: the kernel moves float4
         rows.append([0, 0, 0, 0, 0, 0, off, 0])
         plan = {
             "entries": entries, "total": off, "n": len(entries), "device": dev,

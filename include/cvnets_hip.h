@@ -105,6 +105,49 @@ int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const flo
 int cvh_bn_bwd_apply(int dtype, const void* x, const void* dout, const float* scale, const float* shift, int act, const float* ca,
                      const float* cb, const float* cc, void* dx, long long rows, int C, void* stream);
 
+/* ---- BatchNorm links: train-mode BatchNorm folded into the kernels on either side of it -------------- */
+/* ConvLayer2d stacks (conv -> BN -> SiLU -> conv ..., cvnets/layers/conv_layer.py:254-255; InvertedResidual.forward,
+ * cvnets/modules/mobilenetv2.py:231-235) with NO standalone BatchNorm pass over the activations: a producer kernel emits the column
+ * statistics of the tensor it writes as per-workgroup partial rows (finalised by cvh_bn_finalize / cvh_bn_bwd_finalize, which only
+ * touch [rows][2][C] floats); the consumer applies the resulting per-channel coefficients while loading its operand
+ * (cvh_operand_xf).  Only raw conv outputs (forward) and the activation-gradient products g = dz * act'(bn(y)) (backward) ever reach
+ * HBM.  The struct lives in HOST memory; the pointers inside are device pointers. */
+typedef struct cvh_operand_xf {
+  int mode;           /* 0: v = a;  1: v = act(c0*a + c1);  2: v = c0*a + c1*src2 + c2   (c* indexed by the operand's channel) */
+  const void* src2;   /* second source tensor, same shape / dtype as the operand (mode 2) */
+  const float* c0;
+  const float* c1;
+  const float* c2;
+  int act;            /* CVH_ACT_* (mode 1) */
+} cvh_operand_xf;
+/* Pointwise conv / linear GEMM with operand transform:
+ *   out[M][N] = epilogue( xf(a)[M][K] x wgt[N][K]^T )   (wgt = mode-0 pack for forward, mode-1 pack for dX)
+ *   e_mode 0: store (+residual); stats_part[cvh_conv_gemm_grid_rows(M,N)][2][N] receives (sum, sumsq) of the stored values;
+ *   e_mode 1: BatchNorm-backward epilogue: g = acc * act'(e_aux*scale + shift) is stored, e_aux[M][N] = raw output of the BatchNorm'd
+ *             conv, e_stats[4][N] = its forward statistics (mean, invstd, scale, shift); stats_part receives (sum g, sum g*xhat)
+ *             — the input of cvh_bn_bwd_finalize.
+ * stats_part may be NULL.  Replaces Conv2d(1x1) forward / dX + the BatchNorm passes around it. */
+int cvh_pw_gemm_bn(int dtype, const void* a, const cvh_operand_xf* a_xf, int K, const void* wgt, void* out, long long M, int N,
+                   const void* residual, int e_mode, const void* e_aux, const float* e_stats, int e_act, float* stats_part,
+                   void* stream);
+/* dW[N][Cin_real] = (accumulate ? dW : 0) + xf(dy)[M][N]^T x xf(x)[M][K]  (scratch as in cvh_gemm_dw) */
+int cvh_pw_gemm_dw_bn(int dtype, const void* dy, const cvh_operand_xf* dy_xf, const void* x, const cvh_operand_xf* x_xf, float* dw,
+                      long long M, int N, int K, int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream);
+/* Depthwise 3x3 (pad 1, stride 1 / 2) on LDS-staged tiles: y = dwconv(xf(x)); stats_part[cvh_dwconv_bn_rows()][2][C] receives
+ * (sum, sumsq) of y (NULL: skip). */
+int cvh_dwconv_bn_rows(int B, int Ho, int Wo, int C, int stride);
+int cvh_dwconv_bn_fwd(int dtype, const void* x, const cvh_operand_xf* x_xf, const void* wp, void* y, int B, int H, int W, int Ho, int Wo,
+                      int C, int stride, float* stats_part, void* stream);
+/* Backward of the same conv in ONE pass over its operands: dy = xf(g_out) (mode 2: ca*g_out + cb*y_out + cc; mode 0: g_out is dy),
+ * z = act(scale*x_raw + shift) from in_stats[4][C] (the BatchNorm in FRONT of the conv, required):
+ *   g_in = dwconv^T(dy) * act'(scale*x_raw + shift) is stored;
+ *   stats_part[rows][2][C] receives (sum g_in, sum g_in*xhat) (input of cvh_bn_bwd_finalize);
+ *   dw_part[rows][C*9] receives each workgroup's share of dW[c][tap] = sum_pixels dy * z(shifted) (sum the rows with cvh_sum_partials;
+ *   torch layout [C][1][3][3]);  rows = cvh_dwconv_bn_rows(). */
+int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand_xf* dy_xf, const void* x_raw, const float* in_stats, int in_act,
+                      const void* wp, void* g_in, float* stats_part, float* dw_part, int B, int H, int W, int Ho, int Wo, int C, int stride,
+                      void* stream);
+
 /* ---- reductions / small ops --------------------------------------------------------------------- */
 /* `accumulate` != 0: results are ADDED to the destination (parameter gradients written straight into .grad buffers) */
 int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, int accumulate, void* stream); /* bias grads */

@@ -76,6 +76,24 @@ template <> __device__ __forceinline__ V8<float> v8_zero<float>() {
 }
 template <typename T> __device__ __forceinline__ V8<T> v8_load(const T* p) { return *reinterpret_cast<const V8<T>*>(p); }
 template <typename T> __device__ __forceinline__ void v8_store(T* p, const V8<T>& v) { *reinterpret_cast<V8<T>*>(p) = v; }
+// branch-free predicated load, in two halves so that the load stays a PREFETCH: v8_load_clamped reads base[ok ? off : 0 ...] (always
+// a valid address) and returns whatever is there; v8_mask zeroes it where the value is CONSUMED.  (Conditional per-element loads of
+// several register arrays in one loop make the optimizer sink them behind pointer phis, which pins the arrays in scratch memory;
+// masking right at the load would make the wave wait for the data on the spot.)
+template <typename T> __device__ __forceinline__ V8<T> v8_load_clamped(const T* base, size_t off, bool ok) {
+  return *reinterpret_cast<const V8<T>*>(base + (ok ? off : (size_t)0));
+}
+__device__ __forceinline__ V8<bf16_t> v8_mask(V8<bf16_t> v, bool ok) {
+  const uint32_t m = ok ? 0xffffffffu : 0u;
+  v.d.x &= m; v.d.y &= m; v.d.z &= m; v.d.w &= m;
+  return v;
+}
+__device__ __forceinline__ V8<float> v8_mask(V8<float> v, bool ok) {
+  return ok ? v : v8_zero<float>();
+}
+template <typename T> __device__ __forceinline__ V8<T> v8_load_if(const T* base, size_t off, bool ok) {  // load + mask (no prefetch distance needed)
+  return v8_mask(v8_load_clamped<T>(base, off, ok), ok);
+}
 template <typename T> __device__ __forceinline__ V4<T> v4_load(const T* p) { return *reinterpret_cast<const V4<T>*>(p); }
 template <typename T> __device__ __forceinline__ void v4_store(T* p, const V4<T>& v) { *reinterpret_cast<V4<T>*>(p) = v; }
 
@@ -117,7 +135,10 @@ __device__ __forceinline__ void v4_pack(const float* f, V4<float>& v) { v.a = ma
 // ---------------------------------------------------------------------------------------------
 // activations (fp32 math)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid through the hardware reciprocal (v_rcp_f32, 1 ulp): the plain `1.0f / (...)` expands into the ~10-instruction IEEE
+// division sequence (v_div_scale / v_div_fmas / v_div_fixup), which made every SiLU-bearing kernel VALU-bound on this chip
+// (HBM : VALU is ~14 fp32 ops per byte).  exp(-x) overflows to +inf for x < -88 -> rcp(inf) = 0, the correct limit.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_fwd(float x, int act) {
   if (act == CVH_ACT_SILU) return x * sigmoidf_(x);
   if (act == CVH_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));  // exact erf GELU
@@ -134,6 +155,34 @@ __device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
     return cdf + x * pdf;
   }
   return 1.0f;
+}
+// 8-wide forms: ONE (wave-uniform) dispatch on `act` per vector instead of one per element — the per-element scalar branches
+// chop the unrolled element loops into basic blocks and leave the VALU without independent work to interleave
+__device__ __forceinline__ void act_fwd8(float* v, int act) {
+  if (act == CVH_ACT_SILU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
+  } else if (act == CVH_ACT_GELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+  }
+}
+// g[j] *= act'(x[j])
+__device__ __forceinline__ void act_grad8_mul(float* g, const float* x, int act) {
+  if (act == CVH_ACT_SILU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = sigmoidf_(x[j]);
+      g[j] *= s * (1.0f + x[j] * (1.0f - s));
+    }
+  } else if (act == CVH_ACT_GELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cdf = 0.5f * (1.0f + erff(x[j] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * x[j] * x[j]);
+      g[j] *= cdf + x[j] * pdf;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

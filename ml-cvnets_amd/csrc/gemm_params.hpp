@@ -1,6 +1,7 @@
 // Parameter block shared by the implicit-GEMM kernels (gemm.hip) and the large-tile linear kernel (gemm_big.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "bnlink.hpp"
 
 struct ConvGemmParams {
   const void* src1;
@@ -24,7 +25,17 @@ struct ConvGemmParams {
   // output scatter (dX of a non-overlapping strided conv, kernel == stride, pad 0): GEMM row m = (b, ho, wo) of the sc_Ho x sc_Wo
   // map, column n = (kh, kw, c) -> out[b][ho*sc_s + kh][wo*sc_s + kw][c] of a sc_H x sc_W x sc_C map.  sc_s == 0: plain [M][N] output.
   int sc_s, sc_KW, sc_C, sc_H, sc_W, sc_Ho, sc_Wo;
+  // BatchNorm links (conv_gemm_kernel<..., FX = 1>, pointwise GEMMs only; bnlink.hpp)
+  OperandXf a_xf;        // transform of the A operand on load
+  int e_mode;            // 0: plain epilogue (stats_part: sum, sumsq of the stored values); 1: BatchNorm-backward epilogue (sum g, sum g*xhat)
+  const void* e_aux;     // [M][N] raw output of the BatchNorm'd conv (e_mode 1)
+  const float* e_stats;  // [4][N] its forward statistics (mean, invstd, scale, shift)
+  int e_act;
 };
+inline void conv_gemm_params_no_fx(ConvGemmParams& p) {
+  p.a_xf = make_xf(nullptr);
+  p.e_mode = 0; p.e_aux = nullptr; p.e_stats = nullptr; p.e_act = 0;
+}
 
 struct GemmTNParams {
   const void* dy;
@@ -38,6 +49,7 @@ struct GemmTNParams {
   int m_per_split;
   int k_tiles;
   float* part;  // [splits][N][Ktot] partial products (no atomics); nullptr -> fp32 atomics straight into dw
+  OperandXf dy_xf, x_xf;  // gemm_tn_kernel<..., FX = 1>: operand transforms on load (pointwise only)
 };
 
 // gemm_big.hip

@@ -82,9 +82,19 @@ SIGNATURES = {
     "cvh_rows_copy": [I, P, P, L, I, L, L, P],
     "cvh_embed_lookup_fwd": [I, P, P, P, P, L, I, I, P],
     "cvh_embed_lookup_bwd": [I, P, P, P, L, I, L, P],
+    "cvh_pw_gemm_bn": [I, P, P, I, P, P, L, I, P, I, P, P, I, P, P],
+    "cvh_pw_gemm_dw_bn": [I, P, P, P, P, P, L, I, I, I, P, L, I, P],
+    "cvh_dwconv_bn_rows": [I, I, I, I, I],
+    "cvh_dwconv_bn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, P, P],
+    "cvh_dwconv_bn_bwd": [I, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "cvh_attn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
 }
+
+class OperandXf(ctypes.Structure):
+    """cvh_operand_xf (include/cvnets_hip.h): transform applied to a kernel operand while it is loaded."""
+    _fields_ = [("mode", c_int), ("src2", c_void_p), ("c0", c_void_p), ("c1", c_void_p), ("c2", c_void_p), ("act", c_int)]
+
 
 _lib = None
 

@@ -1,0 +1,179 @@
+"""Block-level autograd functions built on BatchNorm links (csrc/bnlink.hpp): conv -> BN -> act chains whose BatchNorm passes live
+inside the neighbouring conv kernels.
+
+``InvertedResidualFn`` is InvertedResidual.forward (cvnets/modules/mobilenetv2.py:231-235) — exp 1x1-BN-act -> depthwise 3x3-BN-act
+-> red 1x1-BN (+x) — as ONE autograd node.  HBM traffic of the 4x-expanded tensors (fused vs the per-layer path of ops.py):
+
+    forward   write y1, read y1, write y2, read y2                                   (4 wide passes instead of 8)
+    backward  dX3: read y2, write g2 | dW3: read y2 | depthwise: read g2, y2, y1, write g1 | dW1, dX1: read g1, y1 each
+                                                                                      (11 wide passes instead of 18)
+
+where y = raw conv outputs and g = dz * act'(bn(y)).  Normalised activations and BatchNorm input gradients are formed on load by the
+consumer (cvh_operand_xf); statistics leave the producer's epilogue as per-workgroup partial rows and are finalised by the tiny
+cvh_bn_finalize / cvh_bn_bwd_finalize launches.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from .ops import ACT_NONE, _dt, _f32, _p, _stream
+
+def _xf(mode: int = 0, src2=None, c0=None, c1=None, c2=None, act: int = 0):
+    if mode == 0:
+        return None
+    return ctypes.byref(_lib.OperandXf(mode, _p(src2), _p(c0), _p(c1), _p(c2), int(act)))
+
+
+def _pw_gemm(a, a_xf, K, wp, out, M, N, *, residual=None, e_mode=0, e_aux=None, e_stats=None, e_act=0, want_stats=False):
+    """returns (partial statistics rows, R) of the epilogue (or (None, 0))"""
+    part, R = None, 0
+    if want_stats:
+        R = _lib.query("cvh_conv_gemm_grid_rows", int(M), int(N))
+        part = _f32(R * 2 * N, out.device)
+    _lib.call("cvh_pw_gemm_bn", _dt(out), _p(a), a_xf, int(K), _p(wp), _p(out), int(M), int(N), _p(residual), int(e_mode), _p(e_aux),
+              _p(e_stats), int(e_act), _p(part), _stream())
+    return part, R
+
+
+def _bwd_finalize(part, R, C, count, gamma, stats, pg, pb, training):
+    """(sum g, sum g*xhat) partial rows -> dgamma, dbeta (in place when the parameters have gradient sinks) and coef[3][C]"""
+    dev = part.device
+    sg, sb = ops._grad_sink(pg), ops._grad_sink(pb)
+    inplace = sg is not None and sb is not None
+    dgamma = sg if inplace else _f32(C, dev)
+    dbeta = sb if inplace else _f32(C, dev)
+    coef = _f32(3, dev, C)
+    _lib.call("cvh_bn_bwd_finalize", _p(part), R, C, float(count), _p(gamma), _p(stats[0]), _p(stats[1]), 1 if training else 0,
+              1 if inplace else 0, _p(dgamma), _p(dbeta), _p(coef[0]), _p(coef[1]), _p(coef[2]), _stream())
+    if inplace:
+        return coef, None, None
+    return coef, dgamma, dbeta
+
+
+def _pw_weight_grad(dy, dy_xf_args, x, x_xf_args, weight, M, N, K):
+    """dW of a pointwise conv with both operands transformed on load; returns the gradient or None (added in place, side stream)."""
+    sink = ops._grad_sink(weight)
+    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", int(M), int(N), int(K))
+    Cin_real = weight.shape[1]
+
+    def launch(dw, accumulate):
+        scr = _f32(max(n_scr, 1), dy.device)
+        _lib.call("cvh_pw_gemm_dw_bn", _dt(dy), _p(dy), _xf(*dy_xf_args), _p(x), _xf(*x_xf_args), _p(dw), int(M), int(N), int(K),
+                  int(Cin_real), _p(scr), n_scr, accumulate, _stream())
+
+    side = ops._param_grad_stream(dy.device) if sink is not None else None
+    if side is not None:
+        with torch.cuda.stream(side):
+            for t in (dy, x) + tuple(dy_xf_args[1:]) + tuple(x_xf_args[1:]):  # everything the side-stream launch reads
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(side)
+            launch(sink, 1)
+        return None
+    if sink is not None:
+        launch(sink, 1)
+        return None
+    dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
+    launch(dw, 0)
+    return dw
+
+
+class InvertedResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg):
+        stride, use_res, training, act1, act2, mom, eps = cfg
+        ops._check_dev(x)
+        B, Cin, H, W = x.shape
+        hid, Cout = w1.shape[0], w3.shape[0]
+        if ops.pad8(w1.shape[1]) != Cin or hid % 8 or Cout % 8:
+            raise RuntimeError("InvertedResidualFn: channel counts must be multiples of 8")
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        M1, M2 = B * H * W, B * Ho * Wo
+        dev, dt = x.device, x.dtype
+        wp1, wpd, wp3 = ops.pack_weight(w1, dt, 0), ops.pack_weight(wd, dt, 2), ops.pack_weight(w3, dt, 0)
+        if not training:
+            sts = []
+            for g, b, rm, rv, e, C in ((g1, b1, rm1, rv1, eps[0], hid), (g2, b2, rm2, rv2, eps[1], hid), (g3, b3, rm3, rv3, eps[2], Cout)):
+                st = _f32(4, dev, C)
+                _lib.call("cvh_bn_eval_coeff", _p(g), _p(b), _p(rm), _p(rv), float(e), C, _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
+                          _stream())
+                sts.append(st)
+            st1, st2, st3 = sts
+        y1 = ops.nhwc_empty(B, hid, H, W, dt, dev)
+        part, R = _pw_gemm(x, None, Cin, wp1, y1, M1, hid, want_stats=training)
+        if training:
+            st1 = ops._bn_forward(y1, M1, hid, part, R, g1, b1, rm1, rv1, True, mom[0], eps[0])
+        y2 = ops.nhwc_empty(B, hid, Ho, Wo, dt, dev)
+        part, R = None, 0
+        if training:
+            R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
+            part = _f32(R * 2 * hid, dev)
+        _lib.call("cvh_dwconv_bn_fwd", _dt(x), _p(y1), _xf(1, None, st1[2], st1[3], None, act1), _p(wpd), _p(y2), B, H, W, Ho, Wo, hid,
+                  stride, _p(part), _stream())
+        if training:
+            st2 = ops._bn_forward(y2, M2, hid, part, R, g2, b2, rm2, rv2, True, mom[1], eps[1])
+        y3 = ops.nhwc_empty(B, Cout, Ho, Wo, dt, dev)
+        part, R = _pw_gemm(y2, _xf(1, None, st2[2], st2[3], None, act2), hid, wp3, y3, M2, Cout, want_stats=training)
+        if training:
+            st3 = ops._bn_forward(y3, M2, Cout, part, R, g3, b3, rm3, rv3, True, mom[2], eps[2])
+        out = ops.nhwc_empty(B, Cout, Ho, Wo, dt, dev)
+        _lib.call("cvh_bn_apply", _dt(y3), _p(y3), _p(st3[2]), _p(st3[3]), ACT_NONE, _p(x if use_res else None), _p(out), M2, Cout,
+                  _stream())
+        ctx.cfg = cfg
+        ctx.geom = (B, Cin, H, W, Ho, Wo, hid, Cout)
+        ctx.params = (g1, b1, g2, b2, g3, b3)
+        ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        stride, use_res, training, act1, act2, mom, eps = ctx.cfg
+        B, Cin, H, W, Ho, Wo, hid, Cout = ctx.geom
+        x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3 = ctx.saved_tensors
+        pg1, pb1, pg2, pb2, pg3, pb3 = ctx.params
+        dout = ops.as_nhwc(dout)
+        dev, dt = dout.device, dout.dtype
+        M1, M2 = B * H * W, B * Ho * Wo
+        # BatchNorm of the projection conv: narrow tensor, standalone passes
+        dy3, dg3, db3 = ops._bn_backward(y3, dout, st3, g3, ACT_NONE, M2, Cout, training, beta=pb3)
+        # dW3 = dy3^T x act(bn2(y2))
+        dw3 = _pw_weight_grad(dy3, (0,), y2, (1, None, st2[2], st2[3], None, act2), w3, M2, Cout, hid)
+        # g2 = (dy3 W3) * act2'(bn2(y2)) with (sum g2, sum g2*xhat2) from the same epilogue
+        g2t = torch.empty_like(y2)
+        part, R = _pw_gemm(dy3, None, Cout, ops.pack_weight(w3, dt, 1), g2t, M2, hid, e_mode=1, e_aux=y2, e_stats=st2, e_act=act2,
+                           want_stats=True)
+        coef2, dg2, db2 = _bwd_finalize(part, R, hid, M2, g2, st2, pg2, pb2, training)
+        # depthwise backward in one pass: dy2 formed on load, g1 out, dW of the depthwise conv, statistics of g1
+        g1t = torch.empty_like(y1)
+        R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
+        part = _f32(R * 2 * hid, dev)
+        dw_part = _f32(R * hid * 9, dev)
+        _lib.call("cvh_dwconv_bn_bwd", _dt(g2t), _p(g2t), _xf(2, y2, coef2[0], coef2[1], coef2[2]), _p(y1), _p(st1), act1,
+                  _p(ops.pack_weight(wd, dt, 2)), _p(g1t), _p(part), _p(dw_part), B, H, W, Ho, Wo, hid, stride, _stream())
+        coef1, dg1, db1 = _bwd_finalize(part, R, hid, M1, g1, st1, pg1, pb1, training)
+        sink = ops._grad_sink(wd)
+        dwd = None if sink is not None else torch.empty(wd.shape, dtype=torch.float32, device=dev)
+        _lib.call("cvh_sum_partials", _p(dw_part), R, hid * 9, hid * 9, _p(sink if sink is not None else dwd), 1.0,
+                  1 if sink is not None else 0, _stream())
+        # expansion conv: dy1 = ca*g1 + cb*y1 + cc formed on load by both of its consumers
+        dy1_args = (2, y1, coef1[0], coef1[1], coef1[2])
+        dw1 = _pw_weight_grad(g1t, dy1_args, x, (0,), w1, M1, hid, Cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.nhwc_empty(B, Cin, H, W, dt, dev)
+            _pw_gemm(g1t, _xf(*dy1_args), hid, ops.pack_weight(w1, dt, 1), dx, M1, Cin, residual=dout if use_res else None)
+        elif use_res:
+            dx = dout
+        return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None)
+
+
+def inverted_residual(x, exp, dw, red, *, stride: int, use_res: bool):
+    """exp / dw / red: (conv, norm, act_code) triples of the three ConvLayer2d blocks."""
+    (c1, n1, a1), (cd, n2, a2), (c3, n3, _) = exp, dw, red
+    training = n1.training or not n1.track_running_stats
+    cfg = (int(stride), bool(use_res), bool(training), int(a1), int(a2), (n1.momentum, n2.momentum, n3.momentum), (n1.eps, n2.eps, n3.eps))
+    return InvertedResidualFn.apply(x, c1.weight, n1.weight, n1.bias, n1.running_mean, n1.running_var, cd.weight, n2.weight, n2.bias,
+                                    n2.running_mean, n2.running_var, c3.weight, n3.weight, n3.bias, n3.running_mean, n3.running_var, cfg)

@@ -10,12 +10,18 @@ from typing import Optional, Tuple, Union
 import torch
 from torch import Tensor, nn
 
-from . import ops
+from . import fused, ops
 from .layers import (ConvLayer2d, Dropout, Identity, LayerNorm, LinearLayer, LinearSelfAttention, MultiHeadAttention, act_code,
                      build_activation_layer, get_normalization_layer, opt)
 
 
 _FUSED_FFN_BWD = os.environ.get("CVH_FUSED_FFN_BWD", "1") != "0"  # developer A/B switch
+_FUSED_IR = os.environ.get("CVH_FUSED_IR", "1") != "0"  # developer A/B switch: InvertedResidual through BatchNorm links (fused.py)
+
+
+def set_fused_inverted_residual(flag: bool) -> None:
+    global _FUSED_IR
+    _FUSED_IR = bool(flag)
 
 
 def make_divisible(v: Union[float, int], divisor: Optional[int] = 8, min_value: Optional[Union[float, int]] = None) -> Union[float, int]:
@@ -56,11 +62,37 @@ class InvertedResidual(nn.Module):
         x = ops.to_nhwc(x)
         y = x
         mods = self.block._modules
+        if _FUSED_IR and self._fusable():
+            # BatchNorm links (cvnets_amd/fused.py): the whole block is one autograd node, no standalone BatchNorm pass on the 4x-wide tensors
+            trip = []
+            for name in ("exp_1x1", "conv_3x3", "red_1x1"):
+                blk = mods[name].block
+                norm = blk.norm
+                if norm.training and norm.track_running_stats and not ops.bn_counters_bumped():
+                    norm.num_batches_tracked.add_(1)  # plumbing (scalar counter)
+                trip.append((blk.conv, norm, act_code(getattr(blk, "act", None))))
+            return fused.inverted_residual(x, trip[0], trip[1], trip[2], stride=self.stride, use_res=self.use_res_connect)
         if "exp_1x1" in mods:
             y = mods["exp_1x1"](y)
         y = mods["conv_3x3"](y)
         # the residual add rides in the BN-apply pass of the projection conv
         return mods["red_1x1"](y, residual=x if self.use_res_connect else None)
+
+    def _fusable(self) -> bool:
+        mods = self.block._modules
+        if "exp_1x1" not in mods or self.dilation != 1:
+            return False
+        for name in ("exp_1x1", "conv_3x3", "red_1x1"):
+            blk = mods[name].block
+            conv, norm = getattr(blk, "conv", None), getattr(blk, "norm", None)
+            if not isinstance(conv, nn.Conv2d) or conv.bias is not None or not isinstance(norm, nn.BatchNorm2d) or not norm.affine \
+                    or norm.momentum is None or (not norm.track_running_stats and not norm.training):
+                return False
+            if norm.running_mean is None and not norm.training:
+                return False
+            if conv.weight.shape[1] % 8 and conv.groups == 1:
+                return False
+        return mods["red_1x1"].block._modules.get("act") is None
 
     def __repr__(self) -> str:
         return "{}(in_channels={}, out_channels={}, stride={}, exp={}, dilation={}, skip_conn={})".format(

@@ -148,6 +148,17 @@ int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand_xf* dy_xf,
                       const void* wp, void* g_in, float* stats_part, float* dw_part, int B, int H, int W, int Ho, int Wo, int C, int stride,
                       void* stream);
 
+/* Linear side of a BatchNorm link (y = x W^T in front of the BatchNorm, e.g. the 1x1 expansion conv): with coef[3][N] = (ca, cb, cc) of
+ * cvh_bn_bwd_finalize and g = dz * act'(bn(y)),
+ *   dX = g (diag(ca) W) + x (W^T diag(cb) W) + 1 (cc^T W): cvh_bn_dx_weights writes wcat[pad8(K)][N + pad8(K)] (`dtype`) and
+ *        bias[pad8(K)] so that ONE cvh_conv_gemm over the channel-concat (src1 = g, src2 = x) with that weight / bias is dX;
+ *   dW = diag(ca) (g^T x) + diag(cb) W (x^T x) + cc (1^T x): cvh_bn_dw_combine folds P = g^T x [N][K] (cvh_gemm_dw on g), the Gram
+ *        matrix G = x^T x [pad8(K)][pad8(K)] (cvh_gemm_dw on x, x) and the column sums s[pad8(K)] (cvh_colsum) into dw[N][K].
+ * w = float32 [N][K] (torch [N][K][1][1]).  y itself is never read.  Replaces Conv2d(1x1).backward behind a BatchNorm. */
+int cvh_bn_dx_weights(int dtype, const float* w, const float* coef, void* wcat, float* bias, int N, int K, void* stream);
+int cvh_bn_dw_combine(const float* P, const float* w, const float* G, const float* s, const float* coef, float* dw, int N, int K,
+                      int accumulate, void* stream);
+
 /* ---- reductions / small ops --------------------------------------------------------------------- */
 /* `accumulate` != 0: results are ADDED to the destination (parameter gradients written straight into .grad buffers) */
 int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, int accumulate, void* stream); /* bias grads */

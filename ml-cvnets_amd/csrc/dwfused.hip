@@ -42,14 +42,18 @@ struct DwfParams {
   const void* g_out;    // bwd
   const float* in_stats;  // bwd: [4][C] of the BatchNorm in front of the conv
   int in_act;
-  float* stats_part;    // [gridDim.x][2][C] column statistics of the tensor written (nullptr: skip)
-  float* dw_part;       // bwd: [gridDim.x][C*9] this workgroup's share of dW
+  float* stats_part;    // [rows][2][C] column statistics of the tensor written (nullptr: skip); rows = gridDim.x / chunks
+  float* dw_part;       // bwd: [rows][C*9] this workgroup's share of dW
   int B, H, W, Ho, Wo, C;
   int tiles_h, tiles_w;
-  int ntiles, tiles_per_block;
+  int ntiles, chunks;
+  int dbg;  // developer knob (CVH_TUNE key 7): skip phases of the backward kernel to time them (results are WRONG when non-zero)
 };
 
-template <typename T> __host__ __device__ constexpr int dwf_pitch() { return DWF_CC + 16 / (int)sizeof(T); }
+// LDS pixel pitch: 128 B of channels + 32 B.  A pixel lane's 4-pixel stride is then 640 B = 128 B mod 256, so the four pixel lanes
+// of a ds_read_b128 service group (two channel halves each) land on four disjoint 64-byte bank quarters; with a 16-byte pad two
+// of them collided (2-way conflicts on every stencil read).
+template <typename T> __host__ __device__ constexpr int dwf_pitch() { return DWF_CC + 32 / (int)sizeof(T); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Per-channel vectors (coefficients, weights) live in LDS and are read where they are used: held in registers for the whole kernel
@@ -89,7 +93,13 @@ __global__ __launch_bounds__(256, 2) void dwf_fwd_kernel(DwfParams p) {
   float* cst = wl + 9 * DWF_CC;                                   // [2][CC] scale, shift of the input transform
 
   const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;
-  const int c0 = blockIdx.y * DWF_CC, ch = c0 + cl * 8;
+  // Work items = (spatial tile, 64-channel chunk), chunk fastest, handed out ROUND-ROBIN: item = k * gridDim.x + lb.  At any moment the
+  // resident workgroups cover a contiguous run of tiles with all their channel chunks, so DRAM pages are used completely while they are
+  // open (a contiguous private tile range per workgroup — 512 x 30 concurrent 2 KB streams — measured 2.0-2.8 TB/s on loads alone);
+  // lb is XCD-contiguous, so a tile's chunks and its neighbours share one L2.  gridDim.x % chunks == 0: a workgroup's chunk is fixed.
+  const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int chunk = lb % p.chunks, row_id = lb / p.chunks;
+  const int c0 = chunk * DWF_CC, ch = c0 + cl * 8;
   const bool ch_ok = ch < p.C;
   const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
   T* __restrict__ y = reinterpret_cast<T*>(p.y);
@@ -104,12 +114,10 @@ __global__ __launch_bounds__(256, 2) void dwf_fwd_kernel(DwfParams p) {
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   const bool want_stats = p.stats_part != nullptr;
 
-  const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
-  const int t_begin = lb * p.tiles_per_block;
-  const int t_end = min(p.ntiles, t_begin + p.tiles_per_block);
+  const int t_begin = row_id, t_end = p.ntiles, t_step = gridDim.x / p.chunks;
   const int r = pl >> 2, q = pl & 3;
 
-  for (int tix = t_begin; tix < t_end; ++tix) {
+  for (int tix = t_begin; tix < t_end; tix += t_step) {
     const int tw = tix % p.tiles_w;
     const int t1 = tix / p.tiles_w;
     const int th = t1 % p.tiles_h;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void dwf_fwd_kernel(DwfParams p) {
     __syncthreads();
     for (int i = tid; i < 2 * DWF_CC; i += 256) {
       const int which = i / DWF_CC, c = c0 + (i - which * DWF_CC);
-      if (c < p.C) p.stats_part[((size_t)blockIdx.x * 2 + which) * p.C + c] = red[i];
+      if (c < p.C) p.stats_part[((size_t)row_id * 2 + which) * p.C + c] = red[i];
     }
   }
 }
@@ -217,7 +225,13 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
   float* cst = wl + 9 * DWF_CC;                           // [7][CC] mean, invstd, scale, shift (BatchNorm in front); ca, cb, cc (behind)
 
   const int tid = threadIdx.x, cl = tid & 7, pl = tid >> 3;
-  const int c0 = blockIdx.y * DWF_CC, ch = c0 + cl * 8;
+  // Work items = (spatial tile, 64-channel chunk), chunk fastest, handed out ROUND-ROBIN: item = k * gridDim.x + lb.  At any moment the
+  // resident workgroups cover a contiguous run of tiles with all their channel chunks, so DRAM pages are used completely while they are
+  // open (a contiguous private tile range per workgroup — 512 x 30 concurrent 2 KB streams — measured 2.0-2.8 TB/s on loads alone);
+  // lb is XCD-contiguous, so a tile's chunks and its neighbours share one L2.  gridDim.x % chunks == 0: a workgroup's chunk is fixed.
+  const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int chunk = lb % p.chunks, row_id = lb / p.chunks;
+  const int c0 = chunk * DWF_CC, ch = c0 + cl * 8;
   const bool ch_ok = ch < p.C;
   const T* __restrict__ xr = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ go = reinterpret_cast<const T*>(p.g_out);
@@ -242,22 +256,20 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
 
-  const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
-  const int t_begin = lb * p.tiles_per_block;
-  const int t_end = min(p.ntiles, t_begin + p.tiles_per_block);
+  const int t_begin = row_id, t_end = p.ntiles, t_step = gridDim.x / p.chunks;
 
   // g_in = dz * act'(scale*x_raw + shift) for one pixel, stored; statistics of the stored value
-  auto emit = [&](const float* dz, int b, int hi, int wi) __attribute__((always_inline)) {
+  auto emit = [&](const float* dz, const V8<T>& xraw, int b, int hi, int wi) __attribute__((always_inline)) {
     if (hi < p.H && wi < p.W && ch_ok) {
       const size_t o = ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch;
       float xv[8], g[8], sc[8], sh[8];
-      v8_unpack(v8_load<T>(xr + o), xv);
+      v8_unpack(xraw, xv);
       lds_f8(cst + 2 * DWF_CC + cl * 8, sc);
       lds_f8(cst + 3 * DWF_CC + cl * 8, sh);
       float yh[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { g[j] = dz[j]; yh[j] = xv[j] * sc[j] + sh[j]; }
-      act_grad8_mul(g, yh, p.in_act);
+      if (!(p.dbg & 4)) act_grad8_mul(g, yh, p.in_act);
       V8<T> ov;
       v8_pack(g, ov);
       v8_store<T>(gi + o, ov);
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
     }
   };
 
-  for (int tix = t_begin; tix < t_end; ++tix) {
+  for (int tix = t_begin; tix < t_end; tix += t_step) {
     const int tw = tix % p.tiles_w;
     const int t1 = tix / p.tiles_w;
     const int th = t1 % p.tiles_h;
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
 #pragma unroll
         for (int i = 0; i < NLZ; ++i) {
           const int px = (tid + i * 256) >> 3;
-          if (px < NZ) v8_store<T>(zt + px * PITCH + cl * 8, xf_apply<T>(rz[i], rz[i], kz, 1, p.in_act, zok[i]));
+          if (px < NZ) v8_store<T>(zt + px * PITCH + cl * 8, (p.dbg & 8) ? rz[i] : xf_apply<T>(rz[i], rz[i], kz, 1, p.in_act, zok[i]));
         }
       }
       {
@@ -333,13 +345,20 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
     if (S == 1) {
       const int r = pl >> 2, q = pl & 3;  // row r, columns 4q .. 4q+3 (tile coordinates); dy / z tiles are offset by (-1, -1)
       // ---- dX: dz[r][c] = sum_{kh,kw} dy[r + 1 - kh][c + 1 - kw] * w[kh][kw]  ->  dy tile rows r + dh (kh = 2 - dh), cols c + (2 - kw) ----
+      // x_raw at the lane's own pixels (for act' and xhat in the epilogue): requested now, consumed after the dX stencil
+      V8<T> xc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int hi = hi0 + r, wi = wi0 + q * 4 + t;
+        xc[t] = v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, hi < p.H && wi < p.W && ch_ok);
+      }
       float acc[4][8];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
 #pragma unroll 1
-      for (int dh = 0; dh < 3; ++dh) {
+      for (int dh = (p.dbg & 2) ? 3 : 0; dh < 3; ++dh) {
         float wr[3][8];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) lds_f8(wl + ((2 - dh) * 3 + kw) * DWF_CC + cl * 8, wr[kw]);
@@ -359,8 +378,9 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) emit(acc[t], b, hi0 + r, wi0 + q * 4 + t);
+      for (int t = 0; t < 4; ++t) emit(acc[t], xc[t], b, hi0 + r, wi0 + q * 4 + t);
       // ---- dW[kh][kw] += dy[r][c] * z[r - 1 + kh][c - 1 + kw]  (dy tile (r+1, c+1); z tile rows r + kh, cols c + kw) ----
+      if (p.dbg & 1) continue;
       float dyc[4][8];
 #pragma unroll
       for (int t = 0; t < 4; ++t) v8_unpack(v8_load<T>(dt + ((r + 1) * TL::DW + q * 4 + t + 1) * PITCH + cl * 8), dyc[t]);
@@ -416,7 +436,10 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
             }
           }
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq) emit(acc[qq], b, hi0 + 2 * qr + ph, wi0 + 2 * (2 * qc + qq) + pw);
+          for (int qq = 0; qq < 2; ++qq) {
+            const int hi = hi0 + 2 * qr + ph, wi = wi0 + 2 * (2 * qc + qq) + pw;
+            emit(acc[qq], v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, hi < p.H && wi < p.W && ch_ok), b, hi, wi);
+          }
         }
       // dW: owned outputs (qr, 2qc + qq): dW[kh][kw] += dy[ho][wo] * z[2ho - 1 + kh][2wo - 1 + kw] -> z tile (2*qr + kh, 2*wo_l + kw)
 #pragma unroll
@@ -453,11 +476,11 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
   __syncthreads();
   for (int i = tid; i < 2 * DWF_CC; i += 256) {
     const int which = i / DWF_CC, c = c0 + (i - which * DWF_CC);
-    if (c < p.C) p.stats_part[((size_t)blockIdx.x * 2 + which) * p.C + c] = red[i];
+    if (c < p.C) p.stats_part[((size_t)row_id * 2 + which) * p.C + c] = red[i];
   }
   for (int i = tid; i < 9 * DWF_CC; i += 256) {
     const int t = i / DWF_CC, c = c0 + (i - t * DWF_CC);
-    if (c < p.C) p.dw_part[(size_t)blockIdx.x * p.C * 9 + (size_t)c * 9 + t] = dwl[i];
+    if (c < p.C) p.dw_part[(size_t)row_id * p.C * 9 + (size_t)c * 9 + t] = dwl[i];
   }
 }
 
@@ -484,19 +507,18 @@ template <typename K> static int dwf_launch(K kern, size_t smem, dim3 grid, hipS
   return 0;
 }
 
-static void dwf_plan(DwfParams& p, int stride, dim3* grid) {
+static int dwf_plan(DwfParams& p, int stride, dim3* grid) {  // returns the number of partial rows
   const int OH = 8, OW = stride == 1 ? 16 : 8;
   p.tiles_h = (p.Ho + OH - 1) / OH;
   p.tiles_w = (p.Wo + OW - 1) / OW;
   p.ntiles = p.B * p.tiles_h * p.tiles_w;
-  const int chunks = (p.C + DWF_CC - 1) / DWF_CC;
-  int gx = 2048 / chunks;       // ~2048 workgroups in flight-order; rows of the partial-statistics buffers = gx <= 512
-  if (gx > 512) gx = 512;
-  if (gx < 64) gx = 64;
-  if (gx > p.ntiles) gx = p.ntiles;
-  p.tiles_per_block = (p.ntiles + gx - 1) / gx;
-  gx = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
-  *grid = dim3(gx, chunks);
+  p.chunks = (p.C + DWF_CC - 1) / DWF_CC;
+  int rows = 2048 / p.chunks;   // ~2048 workgroups; rows of the partial-statistics buffers <= 512
+  if (rows > 512) rows = 512;
+  if (rows < 32) rows = 32;
+  if (rows > p.ntiles) rows = p.ntiles;
+  *grid = dim3(rows * p.chunks, 1);
+  return rows;
 }
 
 extern "C" int cvh_dwconv_bn_rows(int B, int Ho, int Wo, int C, int stride) {
@@ -504,8 +526,7 @@ extern "C" int cvh_dwconv_bn_rows(int B, int Ho, int Wo, int C, int stride) {
   DwfParams p;
   p.B = B; p.Ho = Ho; p.Wo = Wo; p.C = C;
   dim3 grid;
-  dwf_plan(p, stride, &grid);
-  return (int)grid.x;
+  return dwf_plan(p, stride, &grid);
 }
 
 extern "C" int cvh_dwconv_bn_fwd(int dtype, const void* x, const cvh_operand_xf* x_xf, const void* wp, void* y, int B, int H, int W, int Ho,
@@ -516,6 +537,7 @@ extern "C" int cvh_dwconv_bn_fwd(int dtype, const void* x, const cvh_operand_xf*
   p.x = x; p.xf = make_xf(x_xf); p.wp = wp; p.y = y; p.g_out = nullptr; p.in_stats = nullptr; p.in_act = 0;
   p.stats_part = stats_part; p.dw_part = nullptr;
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.C = C;
+  p.dbg = 0;
   if (p.xf.mode == 2) return -2;
   if (B <= 0) return 0;
   dim3 grid;
@@ -542,6 +564,7 @@ extern "C" int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand
   p.x = x_raw; p.xf = make_xf(dy_xf); p.wp = wp; p.y = g_in; p.g_out = g_out; p.in_stats = in_stats; p.in_act = in_act;
   p.stats_part = stats_part; p.dw_part = dw_part;
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.C = C;
+  p.dbg = cvh_tune_get(7);
   if (p.xf.mode == 1 || (p.xf.mode == 2 && p.xf.src2 == nullptr)) return -2;
   if (B <= 0) return 0;
   dim3 grid;

@@ -201,10 +201,8 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     return -2;
   }
   dim3 grid(out_tiles, splits);
-  if (fx && p.dy_xf.mode == 2) {  // operands transformed on load (BatchNorm links): two-source dY
-    if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0, 2>), grid, dim3(256), 0, st, p);
-    else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 2>), grid, dim3(256), 0, st, p);
-    else return -1;
+  if (fx && p.dy_xf.mode == 2) {
+    return -2;  // not instantiated (see gemm_fx.hip): the linear case goes through cvh_bn_dw_combine
   } else if (fx) {
     if (p.dy_xf.mode != 0) return -2;
     if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0, 1>), grid, dim3(256), 0, st, p);

@@ -84,6 +84,8 @@ SIGNATURES = {
     "cvh_embed_lookup_bwd": [I, P, P, P, L, I, L, P],
     "cvh_pw_gemm_bn": [I, P, P, I, P, P, L, I, P, I, P, P, I, P, P],
     "cvh_pw_gemm_dw_bn": [I, P, P, P, P, P, L, I, I, I, P, L, I, P],
+    "cvh_bn_dx_weights": [I, P, P, P, P, I, I, P],
+    "cvh_bn_dw_combine": [P, P, P, P, P, P, I, I, I, P],
     "cvh_dwconv_bn_rows": [I, I, I, I, I],
     "cvh_dwconv_bn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, P, P],
     "cvh_dwconv_bn_bwd": [I, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, I, P],

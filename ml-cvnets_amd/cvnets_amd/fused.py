@@ -81,6 +81,44 @@ def _pw_weight_grad(dy, dy_xf_args, x, x_xf_args, weight, M, N, K):
     return dw
 
 
+def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp):
+    """dW of a 1x1 conv y = x W^T that sits in front of a train-mode BatchNorm, from g = dz * act'(bn(y)) and the backward coefficients
+    coef[3][N] of that BatchNorm:  dW = diag(ca) (g^T x) + diag(cb) W (x^T x) + cc (1^T x)  — y is not read (csrc/bnlink.hip)."""
+    sink = ops._grad_sink(weight)
+    Kr = weight.shape[1]
+    dev = g.device
+
+    def launch(dw, accumulate):
+        def gemm_dw(dy, n_cols, cin_real):
+            out = torch.empty(n_cols * cin_real, dtype=torch.float32, device=dev)
+            n_scr = _lib.query("cvh_gemm_dw_scratch_elems", int(M), int(n_cols), int(Kp))
+            scr = _f32(max(n_scr, 1), dev)
+            _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), None, Kp, 0, _p(out), int(M), 1, 1, 1, 1, 1, 1, 1, 0, 1, int(n_cols), int(cin_real),
+                      _p(scr), n_scr, 0, _stream())
+            return out
+        P = gemm_dw(g, N, Kr)      # g^T x   [N][Kr]
+        G = gemm_dw(x, Kp, Kp)     # x^T x   [Kp][Kp]
+        R = _lib.query("cvh_colreduce_rows", int(M), int(Kp))
+        part = _f32(R * 2 * Kp, dev)
+        s_ = _f32(Kp, dev)
+        _lib.call("cvh_colsum", _dt(x), _p(x), int(M), int(Kp), _p(part), _p(s_), 1.0, 0, _stream())
+        _lib.call("cvh_bn_dw_combine", _p(P), _p(weight), _p(G), _p(s_), _p(coef), _p(dw), int(N), int(Kr), accumulate, _stream())
+
+    side = ops._param_grad_stream(dev) if sink is not None else None
+    if side is not None:
+        with torch.cuda.stream(side):
+            for t in (g, x, coef):
+                t.record_stream(side)
+            launch(sink, 1)
+        return None
+    if sink is not None:
+        launch(sink, 1)
+        return None
+    dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+    launch(dw, 0)
+    return dw
+
+
 class InvertedResidualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg):
@@ -158,13 +196,16 @@ class InvertedResidualFn(torch.autograd.Function):
         dwd = None if sink is not None else torch.empty(wd.shape, dtype=torch.float32, device=dev)
         _lib.call("cvh_sum_partials", _p(dw_part), R, hid * 9, hid * 9, _p(sink if sink is not None else dwd), 1.0,
                   1 if sink is not None else 0, _stream())
-        # expansion conv: dy1 = ca*g1 + cb*y1 + cc formed on load by both of its consumers
-        dy1_args = (2, y1, coef1[0], coef1[1], coef1[2])
-        dw1 = _pw_weight_grad(g1t, dy1_args, x, (0,), w1, M1, hid, Cin)
+        # expansion conv (LINEAR in x): dy1 = ca*g1 + cb*y1 + cc is never formed and y1 is never re-read — dX1 is one plain GEMM over
+        # the channel-concat [g1 | x] with a small derived weight, dW1 the plain dW GEMM on g1 plus K x K glue (csrc/bnlink.hip)
+        dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin)
         dx = None
         if ctx.needs_input_grad[0]:
+            wcat = torch.empty(Cin * (hid + Cin), dtype=dt, device=dev)
+            bias = _f32(Cin, dev)
+            _lib.call("cvh_bn_dx_weights", _dt(g1t), _p(w1), _p(coef1), _p(wcat), _p(bias), hid, w1.shape[1], _stream())
             dx = ops.nhwc_empty(B, Cin, H, W, dt, dev)
-            _pw_gemm(g1t, _xf(*dy1_args), hid, ops.pack_weight(w1, dt, 1), dx, M1, Cin, residual=dout if use_res else None)
+            ops._conv_gemm(g1t, x, hid, Cin, wcat, dx, M1, 1, 1, 1, 1, 1, 1, 1, 0, 1, Cin, bias=bias, residual=dout if use_res else None)
         elif use_res:
             dx = dout
         return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None)

@@ -1,0 +1,46 @@
+"""microbenchmark of the fused depthwise kernels at MobileViT-S InvertedResidual shapes (developer aid)"""
+import os, sys, ctypes
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+import torch
+from cvnets_amd import _lib, ops, fused
+dt = torch.bfloat16
+dev = "cuda"
+def timeit(fn, reps=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+shapes = [("l1", 128, 64, 128, 128, 1), ("l2.1", 128, 256, 64, 64, 1), ("l2.0", 128, 128, 128, 128, 2)]
+for name, B, C, H, W, S in shapes:
+    Ho, Wo = (H - 1) // S + 1, (W - 1) // S + 1
+    y1 = torch.randn(B, H, W, C, device=dev).to(dt)
+    y2 = torch.randn(B, Ho, Wo, C, device=dev).to(dt)
+    g2 = torch.randn(B, Ho, Wo, C, device=dev).to(dt)
+    g1 = torch.empty_like(y1)
+    st1 = torch.randn(4, C, device=dev).abs() + 0.5
+    coef2 = torch.randn(3, C, device=dev) * 0.1
+    wd = torch.randn(9, C, device=dev).to(dt)
+    R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, C, S)
+    part = torch.empty(R * 2 * C, device=dev)
+    dwp = torch.empty(R * C * 9, device=dev)
+    nbytes_b = (2 * y2.numel() + 2 * y1.numel()) * 2
+    nbytes_f = (y1.numel() + y2.numel()) * 2
+    xf2 = _lib.OperandXf(2, y2.data_ptr(), coef2[0].data_ptr(), coef2[1].data_ptr(), coef2[2].data_ptr(), 0)
+    xf1 = _lib.OperandXf(1, None, st1[2].data_ptr(), st1[3].data_ptr(), None, 1)
+    st = torch.cuda.current_stream().cuda_stream
+    def bwd():
+        _lib.call("cvh_dwconv_bn_bwd", 1, g2.data_ptr(), ctypes.byref(xf2), y1.data_ptr(), st1.data_ptr(), 1, wd.data_ptr(), g1.data_ptr(),
+                  part.data_ptr(), dwp.data_ptr(), B, H, W, Ho, Wo, C, S, st)
+    def fwd():
+        _lib.call("cvh_dwconv_bn_fwd", 1, y1.data_ptr(), ctypes.byref(xf1), wd.data_ptr(), y2.data_ptr(), B, H, W, Ho, Wo, C, S, part.data_ptr(), st)
+    t = timeit(fwd)
+    print(f"{name} fwd           {t:8.1f} us  {nbytes_f / t / 1e6:6.2f} TB/s")
+    for mask, label in ((0, "full"), (1, "no dW"), (2, "no dX"), (4, "no act'"), (8, "no z silu"), (15, "loads+stores only"), (3, "no dX no dW")):
+        _lib.load().cvh_set_tuning(7, mask)
+        t = timeit(bwd)
+        print(f"{name} bwd {label:18s} {t:8.1f} us  {nbytes_b / t / 1e6:6.2f} TB/s")
+    _lib.load().cvh_set_tuning(7, 0)

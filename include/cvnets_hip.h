@@ -162,6 +162,26 @@ int cvh_bn_dw_combine(const float* P, const float* w, const float* G, const floa
 /* ---- reductions / small ops --------------------------------------------------------------------- */
 /* `accumulate` != 0: results are ADDED to the destination (parameter gradients written straight into .grad buffers) */
 int cvh_colsum(int dtype, const void* x, long long rows, int C, float* part, float* out, float scale, int accumulate, void* stream); /* bias grads */
+/* Deferred multi-tensor reduction: out = (accumulate ? out : 0) + scale * sum over `rows` partial rows, for up to thousands of small
+ * tensors in ceil(n / CVH_REDUCE_MAX) launches.  kind 0: out[j] = sum_r part[r*row_stride + j], j < n_out.  kind 1: `part` rows are
+ * cvh_gemm_dw split partials [N][KH*KW*Cin] and out is the torch weight gradient [N][Cin_real][KH*KW] (n_out = N*Ktot,
+ * row_stride = N*Ktot).  Producers that can leave their partial rows un-summed: cvh_gemm_dw / cvh_pw_gemm_dw_bn with dw == NULL
+ * (scratch then holds cvh_gemm_dw_scratch_elems / (N*Ktot) rows), cvh_colsum with out == NULL, cvh_layernorm_bwd, cvh_dwconv_bn_bwd.
+ * `descs` is HOST memory (copied into the kernel arguments: hipGraph-capturable). */
+#define CVH_REDUCE_MAX 48
+typedef struct cvh_reduce_desc {
+  const float* part;
+  float* out;
+  long long row_stride;
+  long long n_out;
+  int rows;
+  int kind;
+  int N, Ktot, Cin, Cin_real, khw;
+  float scale;
+  int accumulate;
+  int pad_;
+} cvh_reduce_desc;
+int cvh_reduce_multi(const cvh_reduce_desc* descs, int n, void* stream);
 int cvh_sum_partials(const float* part, int R, int stride, int Wd, float* out, float scale, int accumulate, void* stream);
 /* GlobalPool(mean) cvnets/layers/global_pool.py:60-71 */
 int cvh_pool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, void* stream);

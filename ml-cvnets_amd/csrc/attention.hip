@@ -210,9 +210,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   int* rq = rq_all + wave * 32;
   const int nqb = (p.S + 31) / 32;
   const int nqg = (nqb + NW - 1) / NW;
-  const int qg = blockIdx.x % nqg;
-  const int head = (blockIdx.x / nqg) % p.h;
-  const int s = blockIdx.x / (nqg * p.h);
+  // XCD-contiguous work order: the query groups and heads of one sequence (and the 4 pixel-interleaved sequences of one image) run on
+  // the SAME XCD, so their shared K / V / Q rows are fetched into one L2 once instead of once per XCD (block b runs on XCD b % 8)
+  const int bid = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int qg = bid % nqg;
+  const int head = (bid / nqg) % p.h;
+  const int s = bid / (nqg * p.h);
   const int q0 = (qg * NW + wave) * 32;
   const int q0_last = (qg * NW + NW - 1) * 32;
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
@@ -418,9 +421,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   int* rq = rq_all + wave * 32;
   const int nqb = (p.S + 31) / 32;
   const int nqg = (nqb + NW - 1) / NW;
-  const int qg = blockIdx.x % nqg;
-  const int head = (blockIdx.x / nqg) % p.h;
-  const int s = blockIdx.x / (nqg * p.h);
+  // XCD-contiguous work order: the query groups and heads of one sequence (and the 4 pixel-interleaved sequences of one image) run on
+  // the SAME XCD, so their shared K / V / Q rows are fetched into one L2 once instead of once per XCD (block b runs on XCD b % 8)
+  const int bid = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int qg = bid % nqg;
+  const int head = (bid / nqg) % p.h;
+  const int s = bid / (nqg * p.h);
   const int q0 = (qg * NW + wave) * 32;
   const int q0_last = (qg * NW + NW - 1) * 32;
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
@@ -555,9 +561,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   int* rk = rk_all + wave * 32;
   const int nkb = (p.S + 31) / 32;
   const int nkg = (nkb + NW - 1) / NW;
-  const int kg = blockIdx.x % nkg;
-  const int head = (blockIdx.x / nkg) % p.h;
-  const int s = blockIdx.x / (nkg * p.h);
+  const int bid = xcd_chunk_id(blockIdx.x, gridDim.x);  // XCD-contiguous work order (see attn_fwd_kernel)
+  const int kg = bid % nkg;
+  const int head = (bid / nkg) % p.h;
+  const int s = bid / (nkg * p.h);
   const int k0 = (kg * NW + wave) * 32;
   const int k0_first = kg * NW * 32;
   const T* qkv = reinterpret_cast<const T*>(p.qkv);

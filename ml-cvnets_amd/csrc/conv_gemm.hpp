@@ -40,7 +40,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   T* stg = As + TILE_ELEMS + wave * (32 * SP);  // per-wave PRIVATE output staging: the epilogue needs only wave-level ordering
-  const int n0 = blockIdx.y * BN;
+  // XCD-contiguous work order, N tile fastest: the workgroups that share an M tile (one per N tile) get consecutive logical ids and so
+  // run on the same XCD — the A rows are fetched into ONE L2 instead of once per XCD (hardware: linear workgroup id b -> XCD b % 8)
+  const int bid_ = xcd_chunk_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int bx = bid_ / (int)gridDim.y, by = bid_ % (int)gridDim.y;
+  const int n0 = by * BN;
   const int Cin = p.C1 + p.C2;
   const T* __restrict__ src1 = reinterpret_cast<const T*>(p.src1);
   const T* __restrict__ src2 = reinterpret_cast<const T*>(p.src2);
@@ -172,11 +176,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     }
   };
 
-  if ((int)blockIdx.x < p.m_tiles) {
-    decode_rows(blockIdx.x * BM);
+  if (bx < p.m_tiles) {
+    decode_rows(bx * BM);
     load_tiles(0);
   }
-  for (int tile_m = blockIdx.x; tile_m < p.m_tiles; tile_m += gridDim.x) {
+  for (int tile_m = bx; tile_m < p.m_tiles; tile_m += gridDim.x) {
     const int m0 = tile_m * BM;
 
     f32x16_t acc[NF];
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     for (int col = tid; col < BN; col += 256) {
       int n = n0 + col;
       if (n < p.N) {
-        p.stats_part[(size_t)blockIdx.x * 2 * p.N + n] = red[col];
-        p.stats_part[(size_t)blockIdx.x * 2 * p.N + p.N + n] = red[BN + col];
+        p.stats_part[(size_t)bx * 2 * p.N + n] = red[col];
+        p.stats_part[(size_t)bx * 2 * p.N + p.N + n] = red[BN + col];
       }
     }
   }

@@ -232,14 +232,40 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
 __device__ __forceinline__ double strided_partial_sum(const float* __restrict__ part, int R, size_t stride, size_t off, int rl) {
   double s = 0.0;
   int r = rl;
-  for (; r + 7 * 64 < R; r += 8 * 64) {
-    float v[8];
+  for (; r + 15 * 64 < R; r += 16 * 64) {  // 16 independent loads in flight: these kernels are latency chains, not bandwidth problems
+    float v[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + j * 64) * stride + off];
-    s += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    for (int j = 0; j < 16; ++j) v[j] = part[(size_t)(r + j * 64) * stride + off];
+    s += (double)((((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                  (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]))));
   }
-  for (; r < R; r += 64) s += (double)part[(size_t)r * stride + off];
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {  // tail: still issued together (predicated)
+    const int rr = r + j * 64;
+    v[j] = rr < R ? part[(size_t)rr * stride + off] : 0.f;
+  }
+  s += (double)((((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]))));
   return s;
+}
+// two column sums (columns off_a / off_b of the same partial rows) with all their loads in flight together
+__device__ __forceinline__ void strided_partial_sum2(const float* __restrict__ part, int R, size_t stride, size_t off_a, size_t off_b, int rl,
+                                                     double& sa, double& sb) {
+  sa = sb = 0.0;
+  for (int r = rl; r < R; r += 16 * 64) {
+    float a[16], b[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int rr = r + j * 64;
+      a[j] = rr < R ? part[(size_t)rr * stride + off_a] : 0.f;
+      b[j] = rr < R ? part[(size_t)rr * stride + off_b] : 0.f;
+    }
+    sa += (double)((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+                   (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15]))));
+    sb += (double)((((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) +
+                   (((b[8] + b[9]) + (b[10] + b[11])) + ((b[12] + b[13]) + (b[14] + b[15]))));
+  }
 }
 
 // sum partial rows: part[R][W] -> out[W]  (f64 accumulation); block = 64 columns x 16 row lanes
@@ -260,6 +286,69 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deferred multi-tensor reduction: every "sum the partial rows" tail of a backward pass whose result only the optimizer reads
+// (dW split partials, LayerNorm dgamma / dbeta, bias gradients, depthwise dW) is queued by the host and executed by ONE launch per
+// <= CVH_REDUCE_MAX descriptors at the end of backward, instead of ~140 latency-bound 5-20 us launches per MobileViT-S step.
+// Descriptors travel in the kernel-argument block (no device table: hipGraph-capturable without a host-to-device copy).
+// ---------------------------------------------------------------------------------------------
+struct ReduceMultiArgs {
+  cvh_reduce_desc d[CVH_REDUCE_MAX];
+  int first_block[CVH_REDUCE_MAX + 1];
+  int n;
+};
+// row lanes per output: big tensors have parallelism to spare (one thread per output, 1 KB coalesced rows); small ones split the rows
+__host__ __device__ __forceinline__ int reduce_lanes(int rows, long long n_out) {
+  if (n_out >= 32768) return 1;
+  if (n_out >= 4096) return 4;
+  return rows > 128 ? 64 : 16;
+}
+__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceMultiArgs a) {
+  __shared__ double red[256];
+  int lo = 0, hi = a.n - 1;
+  while (lo < hi) {  // last descriptor whose first block <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const cvh_reduce_desc& d = a.d[lo];
+  const int RL = reduce_lanes(d.rows, d.n_out), OL = 256 / RL;
+  const int e = threadIdx.x % OL, rl = threadIdx.x / OL;
+  const long long o = (long long)((int)blockIdx.x - a.first_block[lo]) * OL + e;
+  const float* __restrict__ part = d.part;
+  double s = 0.0;
+  if (o < d.n_out) {
+    int r = rl;
+    for (; r + 7 * RL < d.rows; r += 8 * RL) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + j * RL) * d.row_stride + o];
+      s += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+    }
+    float t = 0.f;
+    for (; r < d.rows; r += RL) t += part[(size_t)r * d.row_stride + o];
+    s += (double)t;
+  }
+  red[rl * OL + e] = s;
+  __syncthreads();
+  for (int h = RL / 2; h > 0; h >>= 1) {  // fixed-order tree: deterministic
+    if (rl < h) red[rl * OL + e] += red[(rl + h) * OL + e];
+    __syncthreads();
+  }
+  if (rl == 0 && o < d.n_out) {
+    const float v = (float)(red[e] * (double)d.scale);
+    float* dst;
+    if (d.kind == 1) {  // conv-weight partials [N][KH*KW*Cin] -> torch [N][Cin_real][KH*KW]
+      const int k = (int)(o % d.Ktot), n = (int)(o / d.Ktot);
+      const int tap = k / d.Cin, c = k - tap * d.Cin;
+      if (c >= d.Cin_real) return;
+      dst = d.out + ((size_t)n * d.Cin_real + c) * d.khw + tap;
+    } else {
+      dst = d.out + o;
+    }
+    *dst = d.accumulate ? *dst + v : v;
+  }
+}
+
 // BatchNorm forward finalize: part[R][2][C] (sum, sumsq) -> mean, invstd, scale, shift; running-stat update.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int R, int C, double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -269,17 +358,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
   double a = 0.0, b = 0.0;
-  if (c < C) {
-    a = strided_partial_sum(part, R, (size_t)2 * C, (size_t)c, rl);
-    b = strided_partial_sum(part, R, (size_t)2 * C, (size_t)C + c, rl);
-  }
+  if (c < C) strided_partial_sum2(part, R, (size_t)2 * C, (size_t)c, (size_t)C + c, rl, a, b);
   red[rl][0][threadIdx.x & 15] = a;
   red[rl][1][threadIdx.x & 15] = b;
   __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {  // tree over the 64 row lanes (fixed order: deterministic)
+    if (rl < o) {
+      red[rl][0][threadIdx.x & 15] += red[rl + o][0][threadIdx.x & 15];
+      red[rl][1][threadIdx.x & 15] += red[rl + o][1][threadIdx.x & 15];
+    }
+    __syncthreads();
+  }
   if (rl == 0 && c < C) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int l = 0; l < 64; ++l) { s1 += red[l][0][threadIdx.x & 15]; s2 += red[l][1][threadIdx.x & 15]; }
+    const double s1 = red[0][0][threadIdx.x & 15], s2 = red[0][1][threadIdx.x & 15];
     double mu = s1 / count;
     double var = s2 / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -362,17 +453,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
   double a = 0.0, b = 0.0;
-  if (c < C) {
-    a = strided_partial_sum(part, R, (size_t)2 * C, (size_t)c, rl);
-    b = strided_partial_sum(part, R, (size_t)2 * C, (size_t)C + c, rl);
-  }
+  if (c < C) strided_partial_sum2(part, R, (size_t)2 * C, (size_t)c, (size_t)C + c, rl, a, b);
   red[rl][0][threadIdx.x & 15] = a;
   red[rl][1][threadIdx.x & 15] = b;
   __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {  // tree over the 64 row lanes (fixed order: deterministic)
+    if (rl < o) {
+      red[rl][0][threadIdx.x & 15] += red[rl + o][0][threadIdx.x & 15];
+      red[rl][1][threadIdx.x & 15] += red[rl + o][1][threadIdx.x & 15];
+    }
+    __syncthreads();
+  }
   if (rl == 0 && c < C) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int l = 0; l < 64; ++l) { s1 += red[l][0][threadIdx.x & 15]; s2 += red[l][1][threadIdx.x & 15]; }
+    const double s1 = red[0][0][threadIdx.x & 15], s2 = red[0][1][threadIdx.x & 15];
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     const double g = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
@@ -689,10 +782,31 @@ extern "C" int cvh_colsum(int dtype, const void* x, long long rows, int C, float
   for (int c0 = 0; c0 < C; c0 += Cb) {
     float* pb = part + (size_t)(c0 / Cb) * g * 2 * Cb;
     DISPATCH_T(dtype, hipLaunchKernelGGL((colreduce_kernel<T, 2>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const T*)x + c0, (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, (size_t)rows, Cb, pb, (size_t)C);)
-    // the plain sums live in the first Cb entries of each 2Cb-wide partial row
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((Cb + 15) / 16), dim3(1024), 0, (hipStream_t)stream, pb, g, 2 * Cb, Cb, out + c0, scale, accumulate);
+    // the plain sums live in the first Cb entries of each 2Cb-wide partial row (out == NULL: the caller reduces the rows itself, e.g.
+    // through cvh_reduce_multi)
+    if (out != nullptr)
+      hipLaunchKernelGGL(sum_partials_kernel, dim3((Cb + 15) / 16), dim3(1024), 0, (hipStream_t)stream, pb, g, 2 * Cb, Cb, out + c0, scale, accumulate);
   }
   CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_reduce_multi(const cvh_reduce_desc* descs, int n, void* stream) {
+  for (int base = 0; base < n; base += CVH_REDUCE_MAX) {
+    ReduceMultiArgs a;
+    a.n = n - base < CVH_REDUCE_MAX ? n - base : CVH_REDUCE_MAX;
+    int blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.d[i] = descs[base + i];
+      if (a.d[i].rows <= 0 || a.d[i].n_out <= 0 || a.d[i].part == nullptr || a.d[i].out == nullptr) return -2;
+      a.first_block[i] = blocks;
+      const int OL = 256 / reduce_lanes(a.d[i].rows, a.d[i].n_out);
+      blocks += (int)((a.d[i].n_out + OL - 1) / OL);
+    }
+    a.first_block[a.n] = blocks;
+    for (int i = a.n; i < CVH_REDUCE_MAX; ++i) { a.d[i] = a.d[0]; a.first_block[i + 1] = blocks; }
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    CVH_CHECK_LAUNCH();
+  }
   return 0;
 }
 extern "C" int cvh_sum_partials(const float* part, int R, int stride, int Wd, float* out, float scale, int accumulate, void* stream) {

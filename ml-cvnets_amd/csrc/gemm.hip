@@ -86,6 +86,10 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   const int nf = choose_nf(N);
   const bool bk64 = p.Ktot >= 64;
   if (dtype == CVH_DT_BF16) {
+    // narrow-output pointwise GEMMs whose K is a little over one 64-wide step (the channel-concat dX of a 1x1 expansion conv:
+    // K = 5 * Cin = 80 / 160): a 128-wide K tile keeps the weights resident for K <= 128 and halves the barriers per byte
+    if (nf <= 2 && p.Ktot > 64 && p.Ktot <= 256 && (p.Ktot % 64) != 0 && p.KH == 1 && p.KW == 1 && cvh_tune_get(8) == 0)
+      return nf == 1 ? launch_conv_gemm<bf16_t, 1, 128, 0>(p, st) : launch_conv_gemm<bf16_t, 2, 128, 0>(p, st);
     return bk64 ? dispatch_conv_gemm_nf<bf16_t, 64, 0>(p, nf, st) : dispatch_conv_gemm_nf<bf16_t, 32, 0>(p, nf, st);
   } else if (dtype == CVH_DT_F32) {
     return dispatch_conv_gemm_nf<float, 32, 0>(p, nf, st);
@@ -217,6 +221,7 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
   } else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 0>), grid, dim3(256), 0, st, p);
   else return -1;
   CVH_CHECK_LAUNCH();
+  if (dw == nullptr) return p.part ? 0 : -2;  // partial tiles only: the caller sums the splits later (cvh_reduce_multi)
   if (p.part && KH * KW == 1 && Cin_real == p.Ktot && ((size_t)N * p.Ktot) % 4 == 0 && splits <= 64 && (size_t)N * p.Ktot >= 65536) {
     const size_t total4 = (size_t)N * p.Ktot / 4;
     int g = (int)((total4 + 255) / 256);

@@ -40,7 +40,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_n = wave >> 1, wave_k = wave & 1;
-  const int tile_n = blockIdx.x / p.k_tiles, tile_k = blockIdx.x % p.k_tiles;
+  // XCD-contiguous work order, output tile fastest: the workgroups that reduce the SAME rows m (one per output tile) run on the same XCD
+  // and share the dY / X rows in its L2 (hardware: linear workgroup id b -> XCD b % 8)
+  const int bid_ = xcd_chunk_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int bx = bid_ % (int)gridDim.x, by = bid_ / (int)gridDim.x;
+  const int tile_n = bx / p.k_tiles, tile_k = bx % p.k_tiles;
   const int n0 = tile_n * 128, k0 = tile_k * 128;
   const int Cin = p.C1 + p.C2;
   const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
 
-  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_begin = by * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
 
   // PF register stages in flight per thread (each = 2 rows of dY + 2 rows of A): the ring is indexed statically by unrolling
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
       const int k = k0 + wave_k * 64 + fk * 32 + (lane & 31);
       if (k >= p.Ktot) continue;
       if (p.part) {  // plain coalesced stores of this split's partial tile; gemm_dw_reduce_kernel sums the splits
-        float* dst = p.part + (size_t)blockIdx.y * p.N * p.Ktot + k;
+        float* dst = p.part + (size_t)by * p.N * p.Ktot + k;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);

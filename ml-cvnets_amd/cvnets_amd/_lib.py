@@ -47,6 +47,7 @@ SIGNATURES = {
     "cvh_bn_bwd_finalize": [P, I, I, D, P, P, P, I, I, P, P, P, P, P, P],
     "cvh_bn_bwd_apply": [I, P, P, P, P, I, P, P, P, P, L, I, P],
     "cvh_colsum": [I, P, L, I, P, P, F, I, P],
+    "cvh_reduce_multi": [P, I, P],
     "cvh_sum_partials": [P, I, I, I, P, F, I, P],
     "cvh_pool_fwd": [I, P, P, I, I, I, P],
     "cvh_pool_bwd": [I, P, P, I, I, I, P],
@@ -96,6 +97,13 @@ SIGNATURES = {
 class OperandXf(ctypes.Structure):
     """cvh_operand_xf (include/cvnets_hip.h): transform applied to a kernel operand while it is loaded."""
     _fields_ = [("mode", c_int), ("src2", c_void_p), ("c0", c_void_p), ("c1", c_void_p), ("c2", c_void_p), ("act", c_int)]
+
+
+class ReduceDesc(ctypes.Structure):
+    """cvh_reduce_desc (include/cvnets_hip.h)."""
+    _fields_ = [("part", c_void_p), ("out", c_void_p), ("row_stride", c_longlong), ("n_out", c_longlong), ("rows", c_int), ("kind", c_int),
+                ("N", c_int), ("Ktot", c_int), ("Cin", c_int), ("Cin_real", c_int), ("khw", c_int), ("scale", c_float),
+                ("accumulate", c_int), ("pad_", c_int)]
 
 
 _lib = None

@@ -62,8 +62,10 @@ def _pw_weight_grad(dy, dy_xf_args, x, x_xf_args, weight, M, N, K):
 
     def launch(dw, accumulate):
         scr = _f32(max(n_scr, 1), dy.device)
-        _lib.call("cvh_pw_gemm_dw_bn", _dt(dy), _p(dy), _xf(*dy_xf_args), _p(x), _xf(*x_xf_args), _p(dw), int(M), int(N), int(K),
-                  int(Cin_real), _p(scr), n_scr, accumulate, _stream())
+        deferred = accumulate and n_scr > 0 and ops.defer_reduce(scr, dw, n_scr // (N * K), N * K, N * K, kind=0 if Cin_real == K else 1, N=N,
+                                                                 Ktot=K, Cin=K, Cin_real=Cin_real, khw=1)
+        _lib.call("cvh_pw_gemm_dw_bn", _dt(dy), _p(dy), _xf(*dy_xf_args), _p(x), _xf(*x_xf_args), None if deferred else _p(dw), int(M), int(N),
+                  int(K), int(Cin_real), _p(scr), n_scr, accumulate, _stream())
 
     side = ops._param_grad_stream(dy.device) if sink is not None else None
     if side is not None:
@@ -194,8 +196,9 @@ class InvertedResidualFn(torch.autograd.Function):
         coef1, dg1, db1 = _bwd_finalize(part, R, hid, M1, g1, st1, pg1, pb1, training)
         sink = ops._grad_sink(wd)
         dwd = None if sink is not None else torch.empty(wd.shape, dtype=torch.float32, device=dev)
-        _lib.call("cvh_sum_partials", _p(dw_part), R, hid * 9, hid * 9, _p(sink if sink is not None else dwd), 1.0,
-                  1 if sink is not None else 0, _stream())
+        if not (sink is not None and ops.defer_reduce(dw_part, sink, R, hid * 9, hid * 9)):
+            _lib.call("cvh_sum_partials", _p(dw_part), R, hid * 9, hid * 9, _p(sink if sink is not None else dwd), 1.0,
+                      1 if sink is not None else 0, _stream())
         # expansion conv (LINEAR in x): dy1 = ca*g1 + cb*y1 + cc is never formed and y1 is never re-read — dX1 is one plain GEMM over
         # the channel-concat [g1 | x] with a small derived weight, dW1 the plain dW GEMM on g1 plus K x K glue (csrc/bnlink.hip)
         dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin)

@@ -349,7 +349,8 @@ def _colsum(x2d: torch.Tensor, rows: int, C: int, sink: Optional[torch.Tensor] =
         with torch.cuda.stream(side):
             part = _f32(R * 2 * C, x2d.device)
             x2d.record_stream(side)
-            _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), _p(sink), 1.0, 1, _stream())
+            deferred = C <= 2048 and defer_reduce(part, sink, R, 2 * C, C)
+            _lib.call("cvh_colsum", _dt(x2d), _p(x2d), rows, C, _p(part), None if deferred else _p(sink), 1.0, 1, _stream())
         return None
     part = _f32(R * 2 * C, x2d.device)
     out = sink if sink is not None else _f32(C, x2d.device)
@@ -377,12 +378,8 @@ def _param_grad_stream(device):
     side = _side_streams.get(device)
     if side is None:
         side = _side_streams[device] = torch.cuda.Stream(device=device)
-    if not _side_join_queued:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_param_grad_stream)
-        except RuntimeError:  # not inside a backward pass (direct Function.backward call in a test)
-            return None
-        _side_join_queued = True
+    if not _ensure_backward_callback():  # not inside a backward pass (direct Function.backward call in a test)
+        return None
     side.wait_stream(torch.cuda.current_stream(device))
     return side
 
@@ -392,6 +389,52 @@ def _join_param_grad_stream():
     _side_join_queued = False
     for dev, side in _side_streams.items():
         torch.cuda.current_stream(dev).wait_stream(side)
+    _flush_deferred_reductions()
+
+
+# Deferred reductions: "sum the partial rows" tails whose result only the optimizer reads (dW split partials, LayerNorm dgamma/dbeta,
+# bias gradients, depthwise dW) are queued during backward and executed by cvh_reduce_multi at the end of it — one launch per 48 tensors
+# instead of ~140 latency-bound launches per MobileViT-S step.  Only with in-place parameter gradients (the result must not be needed by
+# autograd) and inside a backward pass (the flush rides on the engine's end-of-backward callback).
+_DEFER_REDUCTIONS = os.environ.get("CVH_DEFER_REDUCE", "1") != "0"
+_pending_reductions = []
+
+
+def _ensure_backward_callback() -> bool:
+    global _side_join_queued
+    if not _side_join_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_param_grad_stream)
+        except RuntimeError:  # not inside a backward pass
+            return False
+        _side_join_queued = True
+    return True
+
+
+def defer_reduce(part, out, rows, row_stride, n_out, *, kind=0, N=0, Ktot=0, Cin=0, Cin_real=0, khw=1, scale=1.0, part_offset=0) -> bool:
+    """queue  out += scale * sum_r part[part_offset + r*row_stride + j]  (see cvh_reduce_multi); False = caller must reduce now"""
+    if not (_DEFER_REDUCTIONS and _INPLACE_PARAM_GRADS) or not _ensure_backward_callback():
+        return False
+    desc = _lib.ReduceDesc(part.data_ptr() + 4 * int(part_offset), out.data_ptr(), int(row_stride), int(n_out), int(rows), int(kind), int(N), int(Ktot),
+                           int(Cin), int(Cin_real), int(khw), float(scale), 1, 0)
+    part.record_stream(torch.cuda.current_stream(part.device))
+    _pending_reductions.append((desc, part, out))
+    return True
+
+
+def _flush_deferred_reductions() -> None:
+    if not _pending_reductions:
+        return
+    by_dev = {}
+    for item in _pending_reductions:
+        by_dev.setdefault(item[1].device, []).append(item)
+    _pending_reductions.clear()
+    for dev, items in by_dev.items():
+        arr = (_lib.ReduceDesc * len(items))(*[it[0] for it in items])
+        with torch.cuda.device(dev):
+            for it in items:
+                it[1].record_stream(torch.cuda.current_stream(dev))
+            _lib.call("cvh_reduce_multi", arr, len(items), _stream())
 
 
 def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real):
@@ -401,13 +444,18 @@ def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad
     n_scr = _lib.query("cvh_gemm_dw_scratch_elems", B * Ho * Wo, N, KH * KW * (C1 + C2))
     side = _param_grad_stream(dy.device) if sink is not None else None
     if side is not None:
+        Ktot = KH * KW * (C1 + C2)
         with torch.cuda.stream(side):
             scr = _f32(max(n_scr, 1), dy.device)
             for t in (dy, x, x2):
                 if t is not None:
                     t.record_stream(side)
-            _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(sink), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real,
-                      _p(scr), n_scr, 1, _stream())
+            # split partials now, their sum at the end of backward (cvh_reduce_multi) — or right here when deferral is off
+            deferred = n_scr > 0 and defer_reduce(scr, sink, n_scr // (N * Ktot), N * Ktot, N * Ktot,
+                                                  kind=0 if (KH * KW == 1 and Cin_real == Ktot) else 1, N=N, Ktot=Ktot, Cin=C1 + C2,
+                                                  Cin_real=Cin_real, khw=KH * KW)
+            _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, None if deferred else _p(sink), B, H, W, Ho, Wo, KH, KW, stride,
+                      pad, dil, N, Cin_real, _p(scr), n_scr, 1, _stream())
         return None
     dw = sink if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
     scr = _f32(max(n_scr, 1), dy.device)
@@ -600,8 +648,9 @@ class DWConvBNAct(torch.autograd.Function):
         _lib.call("cvh_dwconv_bwd_w", _dt(x), _p(x), _p(dy), _p(part), B, H, W, Ho, Wo, C, K, stride, pad, dil, _stream())
         sink = _grad_sink(weight)
         dw = None if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dev)
-        _lib.call("cvh_sum_partials", _p(part), R, C * K * K, C * K * K, _p(sink if sink is not None else dw), 1.0,
-                  1 if sink is not None else 0, _stream())
+        if not (sink is not None and defer_reduce(part, sink, R, C * K * K, C * K * K)):
+            _lib.call("cvh_sum_partials", _p(part), R, C * K * K, C * K * K, _p(sink if sink is not None else dw), 1.0,
+                      1 if sink is not None else 0, _stream())
         dx = None
         if ctx.needs_input_grad[0]:
             wp = pack_weight(weight, dtype, 2)
@@ -796,8 +845,9 @@ class LayerNormFn(torch.autograd.Function):
         _lib.call("cvh_layernorm_bwd", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _stream())
         sg, sb = _grad_sink(gamma), _grad_sink(ctx.beta)
         if sg is not None and sb is not None:
-            _lib.call("cvh_sum_partials", _p(part), R, 2 * C, C, _p(sg), 1.0, 1, _stream())
-            _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, R, 2 * C, C, _p(sb), 1.0, 1, _stream())
+            if not (defer_reduce(part, sg, R, 2 * C, C) and defer_reduce(part, sb, R, 2 * C, C, part_offset=C)):
+                _lib.call("cvh_sum_partials", _p(part), R, 2 * C, C, _p(sg), 1.0, 1, _stream())
+                _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, R, 2 * C, C, _p(sb), 1.0, 1, _stream())
             return dx, None, None, None
         dgb = _f32(2 * C, x.device)
         _lib.call("cvh_sum_partials", _p(part), R, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())

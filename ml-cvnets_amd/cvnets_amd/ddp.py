@@ -7,10 +7,14 @@ Design for the 8-GPU xGMI mesh (7 links x ~153 GB/s per GPU, point-to-point):
     message — few, large collectives (MobileViT-S: 22.3 MB = 1 bucket at the default 25 MB cap; ViT-B: 14 buckets);
   * buckets are filled in reverse-registration order (≈ autograd order); when the last gradient of a bucket has been
     accumulated its all-reduce is enqueued on a SIDE HIP stream behind an event, overlapping the rest of backward;
-  * ``finish`` (queued as an autograd end-of-backward callback) makes the compute stream wait for the side stream and
-    applies the 1/world_size average;
+  * ``finish`` (queued as an autograd end-of-backward callback) makes the compute stream wait for the side stream; the mean is taken
+    by the collective itself (``ReduceOp.AVG`` on RCCL; gloo, which has no AVG, divides afterwards — CPU tests only);
   * with hipGraph-captured steps (bench.py) hooks do not fire on replay, so ``allreduce_flat`` runs the same buckets
-    right after the replay on the side stream.
+    right after the replay on the side stream (MobileViT-S: one 22 MB message behind a >= 20 ms step);
+  * gradients must stay views of the buckets: a training loop that drops them (``optimizer.zero_grad(set_to_none=True)``, the default
+    of torch >= 2 and of the reference's engine) gets them copied back in and re-pointed before every reduction;
+  * float buffers (BatchNorm running statistics) are made views of ONE flat tensor at construction, so the per-forward rank-0
+    broadcast of main_train.py's DDP (``broadcast_buffers``) is a single collective with no gather / scatter copies.
 """
 from __future__ import annotations
 
@@ -45,12 +49,26 @@ class _Bucket:
         self.params = params
         self.numel = sum(p.numel() for p in params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.views = []
         off = 0
         for p in params:
-            p.grad = self.flat[off: off + p.numel()].view_as(p)
+            v = self.flat[off: off + p.numel()].view_as(p)
+            self.views.append(v)
+            p.grad = v
             off += p.numel()
         self.pending = len(params)
         self.work = None
+
+    def adopt_stray_grads(self) -> None:
+        """re-establish ``p.grad is a view of flat`` (a zero_grad(set_to_none=True) / fresh autograd allocation breaks it)"""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+                p.grad = v
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+                p.grad = v
 
 
 class DistributedDataParallel(nn.Module):
@@ -66,10 +84,23 @@ class DistributedDataParallel(nn.Module):
         self.device = params[0].device
         self.use_side_stream = self.device.type == "cuda"
         self.side_stream = torch.cuda.Stream(device=self.device) if self.use_side_stream else None
+        # float buffers -> views of one flat tensor (one broadcast message per forward, no torch.cat / copy-back)
+        fbufs = [b for b in module.buffers() if b.dtype.is_floating_point and b.device == self.device]
+        self.flat_buffers = None
+        if fbufs:
+            self.flat_buffers = torch.empty(sum(b.numel() for b in fbufs), dtype=fbufs[0].dtype, device=self.device) \
+                if all(b.dtype == fbufs[0].dtype for b in fbufs) else None
+        if self.flat_buffers is not None:
+            off = 0
+            for b in fbufs:
+                self.flat_buffers[off: off + b.numel()].copy_(b.reshape(-1))
+                b.data = self.flat_buffers[off: off + b.numel()].view_as(b)
+                off += b.numel()
         # parameters + buffers start identical on every rank (DDP ctor broadcast)
         if self.world > 1:
-            for t in list(module.parameters()) + list(module.buffers()):
+            for t in list(module.parameters()) + [b for b in module.buffers()]:
                 dist.broadcast(t.data, src=0, group=self.pg)
+        self._avg_op = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(self.pg) == "nccl") else None
         # buckets in reverse registration order: the last layers' gradients are ready first
         cap = int(bucket_cap_mb * 1024 * 1024 / 4)
         self.buckets: List[_Bucket] = []
@@ -103,14 +134,21 @@ class DistributedDataParallel(nn.Module):
             self._launch(b)
 
     def _launch(self, b: _Bucket):
+        b.adopt_stray_grads()
+        op = self._avg_op if self._avg_op is not None else dist.ReduceOp.SUM
         if self.use_side_stream:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side_stream.wait_event(ev)
             with torch.cuda.stream(self.side_stream):
-                b.work = dist.all_reduce(b.flat, group=self.pg, async_op=True)
+                b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         else:
-            b.work = dist.all_reduce(b.flat, group=self.pg, async_op=True)
+            b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
+
+    def _average(self):
+        if self._avg_op is None:  # gloo (CPU tests): no AVG reduction
+            for b in self.buckets:
+                b.flat.div_(self.world)
 
     def finish(self):
         """end of backward: launch whatever was not launched, wait, average."""
@@ -123,8 +161,7 @@ class DistributedDataParallel(nn.Module):
             b.pending = len(b.params)
         if self.use_side_stream:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
-        for b in self.buckets:
-            b.flat.div_(self.world)
+        self._average()
         self._callback_queued = False
 
     # ---- explicit path (after a hipGraph replay) ---------------------------------------------
@@ -138,12 +175,12 @@ class DistributedDataParallel(nn.Module):
             b.work = None
         if self.use_side_stream:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
-        for b in self.buckets:
-            b.flat.div_(self.world)
+        self._average()
 
     def zero_grad(self, set_to_none: bool = False):
         """gradients are views of the flat buckets: zero in place (never set to None)."""
         for b in self.buckets:
+            b.adopt_stray_grads()
             b.flat.zero_()
 
     def grad_bytes(self) -> int:
@@ -151,14 +188,12 @@ class DistributedDataParallel(nn.Module):
 
     def forward(self, *args, **kwargs):
         if self.broadcast_buffers and self.world > 1 and self.training:
-            bufs = [b for b in self.module.buffers() if b.dtype.is_floating_point]
-            if bufs:
-                flat = torch.cat([b.reshape(-1) for b in bufs])
-                dist.broadcast(flat, src=0, group=self.pg)
-                off = 0
-                for b in bufs:
-                    b.copy_(flat[off: off + b.numel()].view_as(b))
-                    off += b.numel()
+            if self.flat_buffers is not None:
+                dist.broadcast(self.flat_buffers, src=0, group=self.pg)  # the buffers ARE views of this tensor
+            else:
+                for b in self.module.buffers():
+                    if b.dtype.is_floating_point:
+                        dist.broadcast(b.data, src=0, group=self.pg)
         return self.module(*args, **kwargs)
 
 

@@ -22,6 +22,9 @@ import torch
 from . import _lib, ops
 from .ops import ACT_NONE, _dt, _f32, _p, _stream
 
+DW_SHAPE_LOG = None  # set to a list to record the plain dW GEMMs launched from this module (bench.py)
+
+
 def _xf(mode: int = 0, src2=None, c0=None, c1=None, c2=None, act: int = 0):
     if mode == 0:
         return None
@@ -92,6 +95,8 @@ def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp):
 
     def launch(dw, accumulate):
         def gemm_dw(dy, n_cols, cin_real):
+            if DW_SHAPE_LOG is not None:  # bench.py's kernel probe: (B, H, W, Ho, Wo, C1, C2, KH, KW, stride, pad, dil, N, Cin_real)
+                DW_SHAPE_LOG.append((int(M), 1, 1, 1, 1, int(Kp), 0, 1, 1, 1, 0, 1, int(n_cols), int(cin_real)))
             out = torch.empty(n_cols * cin_real, dtype=torch.float32, device=dev)
             n_scr = _lib.query("cvh_gemm_dw_scratch_elems", int(M), int(n_cols), int(Kp))
             scr = _f32(max(n_scr, 1), dev)

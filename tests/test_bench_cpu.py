@@ -1,0 +1,42 @@
+"""CPU test of bench.py's launch / rendezvous / timing / reporting control flow (`--dry-run`: gloo, no model, no HIP kernels): the
+multi-GPU code path that the driver runs on an 8-GPU node must (a) spawn its own ranks when no launcher set WORLD_SIZE, (b) report
+n_gpus == N with the all-reduce in the step, (c) refuse to print a line for a world size other than --gpus."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def _line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--batch", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _line(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and "+allreduce" in out["config"]["step"]
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["workload"].endswith("global batch 8")
+    assert abs(out["config"]["allreduce_mean"] - 1.5) < 1e-6  # mean of the rank values 1 and 2: the collective really ran across 2 ranks
+    assert abs(out["value"] - 4 * 2 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3  # whole-job images / max-over-ranks wall time
+
+
+def test_bench_single_rank_line_and_refusal():
+    r = _run(["--steps", "2", "--warmup", "1", "--dry-run", "--batch", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _line(r.stdout)
+    assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "dp1" and "+allreduce" not in out["config"]["step"]
+    # a launcher that provides a different world size than --gpus must not yield a line
+    r = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -167,6 +167,8 @@ class CLIP(nn.Module):
             raise NotImplementedError("dict outputs of the image encoder (neural augmentation) are not on the HIP hot path")
         if text_tokens.dim() == 4:
             raise NotImplementedError("zero-shot evaluation is not on the HIP training hot path")
+        ops.pack_all(self.text_encoder)  # the image encoder packs its own weights; without this the text tower would run on the packs of
+        #                                  whatever step its per-layer cache was filled in (the fused optimizer writes through raw pointers)
         text_embeddings = self.text_encoder(text_tokens=text_tokens, key_padding_mask=padding_mask)
         return {"image": image_embeddings, "text": text_embeddings, "logit_scale": self._exponentiate_and_clip_logits(),
                 "zero_shot_image_logits": None, "augmented_tensor": None}

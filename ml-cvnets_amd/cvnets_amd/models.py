@@ -110,9 +110,10 @@ class MobileViT(nn.Module):
 
     # base_image_encoder.py:261-283
     def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
+        ops.pack_all(self)  # every conv / linear weight packed by one launch for this forward (train AND eval: the fused optimizer / EMA
+        #                     kernels rewrite parameters through raw pointers, a cached pack could be stale)
         if self.training:
             ops.advance_dropout_seed(x.device)
-            ops.pack_all(self)  # every conv / linear weight packed by one launch for this step
             ops.bump_bn_counters(self)
         try:
             x = ops.to_nhwc(x)
@@ -206,9 +207,9 @@ class VisionTransformer(nn.Module):
                 m.eps = 1e-6
 
     def extract_patch_embeddings(self, x: Tensor):
+        ops.pack_all(self)  # train AND eval (see MobileViT.extract_features)
         if self.training:
             ops.advance_dropout_seed(x.device)
-            ops.pack_all(self)
         fm = self.patch_emb(ops.to_nhwc(x))
         B, E, n_h, n_w = fm.shape
         N = n_h * n_w
@@ -318,9 +319,9 @@ class MobileViTv2(nn.Module):
         return nn.Sequential(*block), input_channel
 
     def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
+        ops.pack_all(self)  # train AND eval (see MobileViT.extract_features)
         if self.training:
             ops.advance_dropout_seed(x.device)
-            ops.pack_all(self)
             ops.bump_bn_counters(self)
         try:
             x = ops.to_nhwc(x)

@@ -143,21 +143,33 @@ def nhwc_to_nchw_f32(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # dropout state: one device-resident 64-bit seed per device; masks are f(seed, stream_id, element)
 # ------------------------------------------------------------------------------------------------
-_seeds = {}
 _stream_ids = itertools.count(1)
+_seeds = {}      # device index -> the generator state (advanced once per training forward)
+_seed_snap = {}  # device index -> snapshot of the state taken by the CURRENT forward
 
 
-def dropout_seed(device) -> torch.Tensor:
+def _seed_state(device) -> torch.Tensor:
     key = torch.device(device).index or 0
     if key not in _seeds:
         _seeds[key] = torch.tensor([0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device) + torch.initial_seed()
     return _seeds[key]
 
 
+def dropout_seed(device) -> torch.Tensor:
+    """The seed tensor the dropout masks of the CURRENT forward are drawn from.  Ops save it for their backward, so a later forward
+    (gradient accumulation over several forwards, a second model in train mode, a teacher) cannot change the mask a pending backward
+    regenerates: every training forward snapshots its own copy (`advance_dropout_seed`)."""
+    key = torch.device(device).index or 0
+    snap = _seed_snap.get(key)
+    return snap if snap is not None else _seed_state(device)
+
+
 def advance_dropout_seed(device) -> None:
     """Called once at the start of every training forward (captured into the step's hipGraph, so replays draw
-    fresh masks)."""
-    _lib.call("cvh_seed_advance", _p(dropout_seed(device)), _stream())
+    fresh masks): advances the generator state and snapshots it for this forward."""
+    state = _seed_state(device)
+    _lib.call("cvh_seed_advance", _p(state), _stream())
+    _seed_snap[torch.device(device).index or 0] = state.clone()  # plumbing: 8 bytes
 
 
 def next_stream_id() -> int:
@@ -167,7 +179,16 @@ def next_stream_id() -> int:
 # ------------------------------------------------------------------------------------------------
 # weight packing
 # ------------------------------------------------------------------------------------------------
-_PACKED = {}  # (data_ptr, mode, dtype) -> (packed view, parameter version it was packed from, weakref to the parameter)
+_PACKED = {}  # (data_ptr, mode, dtype) -> (packed view, parameter version it was packed from, weakref to the parameter, pack epoch)
+_PACK_EPOCH = 0  # bumped by everything that rewrites parameters through raw pointers (cvh_adamw_multi, EMA kernels): `_version` cannot see those
+
+
+def invalidate_packed() -> None:
+    """Every cached packed weight becomes stale (call after parameters were updated behind autograd's back: the fused optimizer / EMA
+    kernels do it themselves when stepped eagerly; after hipGraph REPLAYS of a captured optimizer step call it before using layers outside
+    a model-level forward — the model-level forwards re-pack unconditionally)."""
+    global _PACK_EPOCH
+    _PACK_EPOCH += 1
 
 
 def _pack_numel(shape, mode: int) -> int:
@@ -232,7 +253,7 @@ class PackPlan:
             return
         _lib.call("cvh_weight_pack_multi", _dt(self.flat), _p(self.table), len(self.entries), self.total, _p(self.flat), _stream())
         for (w, mode), (off, n) in zip(self.entries, self.offsets):
-            _PACKED[(w.data_ptr(), mode, self.dtype)] = (self.flat[off: off + n], w._version, weakref.ref(w))
+            _PACKED[(w.data_ptr(), mode, self.dtype)] = (self.flat[off: off + n], w._version, weakref.ref(w), _PACK_EPOCH)
 
 
 def pack_all(module: torch.nn.Module, dtype: Optional[torch.dtype] = None) -> None:
@@ -297,7 +318,7 @@ def _grad_sink(param: Optional[torch.Tensor]):
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, mode: int) -> torch.Tensor:
     """mode 0: [Cout][KH*KW][pad8(Cin)] ; mode 1: [Cin][KH*KW][pad8(Cout)] (taps flipped) ; mode 2: depthwise [KH*KW][C]."""
     hit = _PACKED.get((w.data_ptr(), mode, dtype))
-    if hit is not None and hit[1] == w._version and hit[2]() is w:
+    if hit is not None and hit[1] == w._version and hit[2]() is w and hit[3] == _PACK_EPOCH:
         return hit[0]
     wf = w.detach()
     if wf.dtype != torch.float32 or not wf.is_contiguous():
@@ -727,6 +748,7 @@ class LinearAct(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
         ctx.bias = bias
+        ctx.seed = seed  # this forward's snapshot: the backward regenerates exactly this mask
         ctx.save_for_backward(x, weight, pre, in_pre)
         if expose_pre:
             if pre is None:
@@ -750,7 +772,7 @@ class LinearAct(torch.autograd.Function):
             dy = dout
             if drop_p > 0:
                 dy = torch.empty_like(dout)
-                _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(dropout_seed(dev)), stream_id, _stream())
+                _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(ctx.seed), stream_id, _stream())
             if act != ACT_NONE:
                 dy = _act_backward(pre, dy, act, rows, N)
             if expose_pre and dpre is not None:
@@ -1246,7 +1268,9 @@ class DropoutFn(torch.autograd.Function):
         if not (x.is_contiguous() or is_nhwc(x)):
             x = x.contiguous()
         y = torch.empty_like(x)  # same (dense) layout as x: the mask is a function of the MEMORY index, NHWC maps stay NHWC
-        _lib.call("cvh_dropout", _dt(x), _p(x), _p(y), x.numel(), float(p), _p(dropout_seed(x.device)), stream_id, _stream())
+        seed = dropout_seed(x.device)
+        _lib.call("cvh_dropout", _dt(x), _p(x), _p(y), x.numel(), float(p), _p(seed), stream_id, _stream())
+        ctx.seed = seed
         ctx.cfg = (p, stream_id, is_nhwc(x) and not x.is_contiguous())
         return y
 
@@ -1255,7 +1279,7 @@ class DropoutFn(torch.autograd.Function):
         p, stream_id, nhwc = ctx.cfg
         dy = as_nhwc(dy) if nhwc else dy.contiguous()  # the gradient must be walked in the layout the forward mask was drawn in
         dx = torch.empty_like(dy)
-        _lib.call("cvh_dropout", _dt(dy), _p(dy), _p(dx), dy.numel(), float(p), _p(dropout_seed(dy.device)), stream_id, _stream())
+        _lib.call("cvh_dropout", _dt(dy), _p(dy), _p(dx), dy.numel(), float(p), _p(ctx.seed), stream_id, _stream())
         return dx, None, None
 
 

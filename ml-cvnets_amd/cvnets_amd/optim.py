@@ -8,7 +8,7 @@ from typing import Iterable, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .ops import _p, _stream
 
 
@@ -23,18 +23,24 @@ class AdamW(torch.optim.Optimizer):
         if len(b) != 2:
             raise NotImplementedError("per-group betas / eps are not supported (the reference uses one setting, optim/adamw.py:30-40)")
         self._plan = None
+        self._loaded_state = {}
+        self._rebuilds = 0
         self._ema = ema
         self.ema_momentum = float(ema_momentum)
 
     # -------------------------------------------------------------------------------------------------
     def _build(self):
-        entries = []
+        entries, skipped = [], []
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
-                if p.requires_grad:
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:  # torch.optim.AdamW skips parameters without a gradient (no decay of weights or moments): so do we
+                    skipped.append(p)
+                else:
                     entries.append((p, gi))
         if not entries:
-            raise RuntimeError("no trainable parameters")
+            raise RuntimeError("no parameter has a gradient")
         dev = entries[0][0].device
         if dev.type != "cuda":
             raise RuntimeError("cvnets_amd.optim.AdamW has no CPU path")
@@ -45,29 +51,90 @@ class AdamW(torch.optim.Optimizer):
                 if p.shape != e.shape:
                     raise RuntimeError("EMA model does not mirror the model")
                 ema_by_id[id(p)] = e
-        rows, off = [], 0
+        rows, offsets, off = [], [], 0
         for p, gi in entries:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("parameters must be contiguous float32")
-            if p.grad is None:  # plumbing: the kernel reads every gradient, absent ones count as zero
-                p.grad = torch.zeros_like(p)
             e = ema_by_id.get(id(p))
             rows.append([p.data_ptr(), p.grad.data_ptr(), e.data_ptr() if e is not None else 0, off, p.numel(), gi, off, 0])
+            offsets.append(off)
             off += (p.numel() + 3) // 4 * 4  # every tensor starts on a 4-element boundary: the kernel moves float4
         rows.append([0, 0, 0, 0, 0, 0, off, 0])
         plan = {
-            "entries": entries, "total": off, "n": len(entries), "device": dev,
+            "entries": entries, "skipped": skipped, "offsets": offsets, "total": off, "n": len(entries), "device": dev,
             "table": torch.tensor(rows, dtype=torch.int64, device=dev),
             "m": torch.zeros(off, dtype=torch.float32, device=dev), "v": torch.zeros(off, dtype=torch.float32, device=dev),
             "step": torch.zeros(1, dtype=torch.float32, device=dev),
             "hp": torch.zeros(len(self.param_groups), 2, dtype=torch.float32, device=dev),
             "hp_host": None, "grad_ptrs": [p.grad.data_ptr() for p, _ in entries],
         }
+        old = self._plan
+        if old is not None:  # gradients were re-allocated / the set of live parameters changed: carry the moments over per parameter
+            prev = {id(p): o for (p, _), o in zip(old["entries"], old["offsets"])}
+            for (p, _), o in zip(entries, offsets):
+                po = prev.get(id(p))
+                if po is not None:
+                    plan["m"][o: o + p.numel()].copy_(old["m"][po: po + p.numel()])
+                    plan["v"][o: o + p.numel()].copy_(old["v"][po: po + p.numel()])
+            plan["step"] = old["step"]
+            self._rebuilds += 1
+            if self._rebuilds == 3:
+                import warnings
+                warnings.warn("cvnets_amd.optim.AdamW re-plans every step because the gradient tensors keep moving (zero_grad(set_to_none=True)?): "
+                              "keep gradients in place (set_to_none=False or cvnets_amd.ddp's flat buckets) for the one-launch fast path")
         self._plan = plan
+        self._apply_loaded_state()
         return plan
 
     def _valid(self, plan) -> bool:
-        return all(p.grad is not None and p.grad.data_ptr() == gp for (p, _), gp in zip(plan["entries"], plan["grad_ptrs"]))
+        return all(p.grad is not None and p.grad.data_ptr() == gp for (p, _), gp in zip(plan["entries"], plan["grad_ptrs"])) \
+            and all(p.grad is None for p in plan["skipped"])
+
+    # ---- checkpointing: torch.optim.AdamW's state layout (step / exp_avg / exp_avg_sq per parameter index) -------------------------
+    def _param_index(self):
+        idx, i = {}, 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                idx[id(p)] = i
+                i += 1
+        return idx
+
+    def state_dict(self):
+        sd = super().state_dict()
+        plan = self._plan
+        if plan is not None:
+            idx = self._param_index()
+            step = plan["step"].detach().clone().reshape(())
+            sd["state"] = {idx[id(p)]: {"step": step.clone(), "exp_avg": plan["m"][o: o + p.numel()].view_as(p).clone(),
+                                        "exp_avg_sq": plan["v"][o: o + p.numel()].view_as(p).clone()}
+                           for (p, _), o in zip(plan["entries"], plan["offsets"])}
+        elif self._loaded_state:
+            sd["state"] = self._loaded_state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        loaded = dict(state_dict.get("state", {}))
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        self._loaded_state = {int(k): v for k, v in loaded.items()}
+        if self._plan is not None:
+            self._apply_loaded_state()
+            self._plan["hp_host"] = None  # the groups' lr / weight_decay may have changed
+
+    def _apply_loaded_state(self):
+        if not self._loaded_state or self._plan is None:
+            return
+        plan, idx = self._plan, self._param_index()
+        steps = []
+        for (p, _), o in zip(plan["entries"], plan["offsets"]):
+            st = self._loaded_state.get(idx[id(p)])
+            if st is None:
+                continue
+            plan["m"][o: o + p.numel()].copy_(st["exp_avg"].reshape(-1).to(plan["m"]))
+            plan["v"][o: o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(plan["v"]))
+            steps.append(float(st["step"]))
+        if steps:
+            plan["step"].fill_(max(steps))
+        self._loaded_state = {}
 
     def sync_hyperparameters(self) -> None:
         """copy the per-group (lr, weight_decay) to the device table; call after a scheduler changed them (outside graph replay)."""
@@ -82,16 +149,14 @@ class AdamW(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         plan = self._plan
         if plan is None or not self._valid(plan):
-            old = plan
-            plan = self._build()
-            if old is not None and old["total"] == plan["total"]:  # gradients were re-allocated: keep the moments
-                plan["m"], plan["v"], plan["step"] = old["m"], old["v"], old["step"]
+            plan = self._build()  # carries the moments of the previous plan over, parameter by parameter
         if sync_hyperparameters:
             self.sync_hyperparameters()
         g0 = self.param_groups[0]
         _lib.call("cvh_adamw_multi", _p(plan["table"]), plan["n"], plan["total"], _p(plan["m"]), _p(plan["v"]), _p(plan["hp"]),
                   float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _p(plan["step"]), _p(inv_grad_scale),
                   self.ema_momentum if self._ema is not None else 0.0, _stream())
+        ops.invalidate_packed()  # parameters (and EMA parameters) changed through raw pointers: cached packed weights are stale
         return loss
 
 
@@ -118,5 +183,6 @@ class EMABuffers:
     def update(self):
         if self.n:
             _lib.call("cvh_lerp_multi", _p(self.table), self.n, self.total, self.momentum, _stream())
+            ops.invalidate_packed()
         for d, s in self.ints:  # averaging an integer counter is a copy after the cast back (ema_v.copy_(...) on an int64 tensor)
             d.copy_((d * (1.0 - self.momentum) + self.momentum * s).to(d.dtype))

@@ -129,3 +129,49 @@ def test_gather_all_features_gloo_world2():
         assert p.exitcode == 0
     for rank, err, dl in sorted(q.get(timeout=5) for _ in range(2)):
         assert err < 1e-6 and dl < 1e-6, (rank, err, dl)
+
+
+def _stray_worker(rank, world, port, q):
+    """a training loop that drops gradients (optimizer.zero_grad(set_to_none=True), the default of torch >= 2 and of the reference's
+    engine) must still get the cross-rank mean: the wrapper re-adopts freshly allocated .grad tensors into its flat buckets"""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cvnets_amd.ddp import DistributedDataParallel, distributed_init
+
+    distributed_init("gloo", torch.device("cpu"))
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    ok = True
+    for it in range(3):
+        opt.zero_grad()  # set_to_none=True: p.grad = None, autograd allocates new tensors outside the buckets
+        torch.manual_seed(10 * it + rank)
+        x = torch.randn(4, 6)
+        ddp(x).square().mean().backward()
+        g_local_mean = [p.grad.clone() for p in net.parameters()]
+        gathered = [[torch.zeros_like(g) for _ in range(world)] for g in g_local_mean]
+        for g, gl in zip(g_local_mean, gathered):
+            dist.all_gather(gl, g)
+        ok = ok and all(all(torch.allclose(a, gl[0], atol=1e-7) for a in gl) for gl in gathered)  # identical on every rank = reduced
+        ok = ok and all(p.grad.data_ptr() == v.data_ptr() for b in ddp.buckets for p, v in zip(b.params, b.views))
+        opt.step()
+    w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    q.put((rank, bool(ok and torch.allclose(ws[0], ws[1], atol=1e-7))))
+    dist.destroy_process_group()
+
+
+def test_ddp_set_to_none_gradients_are_readopted():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stray_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, ok in sorted(q.get(timeout=5) for _ in range(2)):
+        assert ok, rank

@@ -105,3 +105,117 @@ def test_fused_adamw_inside_a_captured_step():
     torch.cuda.synchronize()
     assert float(opt._plan["step"].item()) == 4.0
     assert l2_err(w.detach().cpu(), w_ref.detach().cpu()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# advisor findings of round 1 (packed-weight cache, optimizer state, set_to_none gradients, dropout seed)
+# ------------------------------------------------------------------------------------------------
+def _tiny_mobilevit(seed=0):
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+
+    torch.manual_seed(seed)
+    opts = default_opts(**{"model.classification.mit.mode": "xx_small", "model.classification.mit.dropout": 0.0,
+                           "model.classification.classifier_dropout": 0.0})
+    return cvnets_amd.MobileViT(opts).cuda()
+
+
+def test_forward_after_fused_step_uses_fresh_weights():
+    """The fused AdamW / EMA kernels write parameters through raw pointers (no autograd version bump): the next forward — train mode of
+    the stepped model, eval mode of the EMA model — must run on the UPDATED weights, not on a packed copy of the old ones."""
+    import cvnets_amd
+    from cvnets_amd.optim import AdamW
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        net = _tiny_mobilevit().train()
+        ema = copy.deepcopy(net).eval()
+        x = torch.randn(4, 3, 32, 32, device="cuda")
+        with torch.no_grad():
+            e0 = ema(x).clone()  # fills the EMA model's packed-weight cache
+            net(x)               # ... and the model's
+        opt = AdamW(net.parameters(), lr=5e-2, ema=(net, ema), ema_momentum=0.5)
+        opt.zero_grad(set_to_none=False)
+        net(x).square().mean().backward()
+        opt.step()
+        # references: fresh copies of the UPDATED parameters (new tensors, nothing cached for them)
+        net_ref, ema_ref = copy.deepcopy(net), copy.deepcopy(ema)
+        with torch.no_grad():
+            y, y_ref = net(x), net_ref(x)      # train-mode forward after the step
+            e1, e1_ref = ema(x), ema_ref(x)    # eval-mode forward of the EMA model after its parameters moved
+        assert l2_err(y, y_ref) < 1e-3  # (stale packs give >= 1e-2; run-to-run round-off through train-mode BatchNorm at batch 4 is ~4e-5)
+        assert l2_err(e1, e1_ref) < 1e-3
+        assert l2_err(e1, e0) > 1e-3, "the EMA model's forward did not change although its parameters did: stale packed weights"
+        # standalone layer (no model-level forward): its per-call packed-weight cache must notice the raw-pointer update as well
+        from cvnets_amd import ops
+        lin_w = torch.randn(16, 8, device="cuda").requires_grad_()
+        xin = torch.randn(4, 8, device="cuda")
+        y0 = ops.linear(xin, lin_w).clone()
+        o2 = AdamW([lin_w], lr=0.5)
+        lin_w.grad = torch.ones_like(lin_w)
+        o2.step()
+        assert l2_err(ops.linear(xin, lin_w), xin @ lin_w.detach().t()) < 1e-5 and l2_err(ops.linear(xin, lin_w), y0) > 1e-2
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+
+
+def test_fused_adamw_state_dict_roundtrip_and_set_to_none():
+    """checkpoint / resume (the reference saves optimizer.state_dict()) and the default zero_grad(set_to_none=True) of torch >= 2"""
+    from cvnets_amd.optim import AdamW
+
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4)).cuda()
+    unused = torch.nn.Parameter(torch.randn(5, device="cuda"))  # never receives a gradient: torch skips it, so must we
+    ref, unused_ref = copy.deepcopy(net), torch.nn.Parameter(unused.detach().clone())
+    opt = AdamW(list(net.parameters()) + [unused], lr=1e-2, weight_decay=0.1)
+    opt_ref = torch.optim.AdamW(list(ref.parameters()) + [unused_ref], lr=1e-2, weight_decay=0.1)
+    x = torch.randn(8, 12, device="cuda")
+
+    def run(m, o, steps):
+        for _ in range(steps):
+            o.zero_grad()  # set_to_none=True: fresh gradient tensors every step
+            m(x).square().mean().backward()
+            o.step()
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        run(net, opt, 3)
+        run(ref, opt_ref, 3)
+    assert torch.equal(unused.detach(), unused_ref.detach())
+    sd = opt.state_dict()
+    sd_ref = opt_ref.state_dict()
+    assert set(sd["state"]) == set(sd_ref["state"])  # the unused parameter has no state in either
+    for k, st in sd["state"].items():
+        assert float(st["step"]) == float(sd_ref["state"][k]["step"]) == 3.0
+        assert l2_err(st["exp_avg"].cpu(), sd_ref["state"][k]["exp_avg"].cpu()) < 1e-4
+        assert l2_err(st["exp_avg_sq"].cpu(), sd_ref["state"][k]["exp_avg_sq"].cpu()) < 1e-4
+    # resume in a fresh optimizer, continue, compare with the uninterrupted torch run
+    net2 = copy.deepcopy(net)
+    opt2 = AdamW(list(net2.parameters()) + [torch.nn.Parameter(unused.detach().clone())], lr=1e-2, weight_decay=0.1)
+    opt2.load_state_dict(sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        run(net2, opt2, 2)
+        run(ref, opt_ref, 2)
+    for a, b in zip(net2.parameters(), ref.parameters()):
+        assert l2_err(a.detach().cpu(), b.detach().cpu()) < 2e-5
+
+
+def test_dropout_mask_survives_a_second_forward():
+    """forward(a), forward(b), backward(a): the mask regenerated in a's backward must be a's, not b's (per-forward seed snapshot)"""
+    import cvnets_amd
+    from cvnets_amd import ops
+
+    x = torch.randn(64, 128, device="cuda", requires_grad=True)
+    w = torch.randn(128, 128, device="cuda") * 0.1
+    ops.advance_dropout_seed(x.device)
+    ya = ops.linear(x, w, drop_p=0.5)
+    keep_a = (ya.detach() != 0)
+    ops.advance_dropout_seed(x.device)      # a second training forward starts (different masks)
+    yb = ops.linear(x.detach(), w, drop_p=0.5)
+    assert (keep_a != (yb != 0)).any()
+    ya.backward(torch.ones_like(ya))
+    # d/dx sum(dropout(x W^T)) = (mask * 2) W: compare with the mask observed in a's forward
+    ref = (keep_a.float() * 2.0) @ w
+    assert l2_err(x.grad, ref) < 1e-4

@@ -46,6 +46,11 @@ _BY_NAME = {
     "TextTransformer": clip.TextTransformer,
     "SimpleImageProjectionHead": clip.SimpleImageProjectionHead,
     "CLIP": clip.CLIP,
+    # parameter-free leaves: swapped too, so that a swapped model holds no reference class at all (it can then be pickled / deep-copied /
+    # shipped to a process that does not have the reference tree, and `act_code` sees the mirrors' own types)
+    "Swish": layers.Swish,
+    "GELU": layers.GELU,
+    "Identity": layers.Identity,
 }
 
 

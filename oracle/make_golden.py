@@ -53,6 +53,19 @@ FULL_GRADS = [
 ]
 
 
+def grad_sample_fields(ref_grads):
+    """large-batch fixtures: every gradient at oracle.weights.sample_indices positions + per-tensor L1 norm and signed sum (for the
+    absolute bf16 bounds and the signed-bias check of tests/test_bf16_parity_gpu.py) — a few hundred KB instead of the full gradients"""
+    from oracle.weights import sample_indices
+    names = list(ref_grads.keys())
+    out = {"grad_l1": np.array([ref_grads[k].double().abs().sum().item() for k in names], dtype=np.float64),
+           "grad_sum": np.array([ref_grads[k].double().sum().item() for k in names], dtype=np.float64),
+           "grad_numel": np.array([ref_grads[k].numel() for k in names], dtype=np.int64)}
+    for k in names:
+        out["gsamp::" + k] = ref_grads[k].reshape(-1)[torch.from_numpy(sample_indices(k, ref_grads[k].numel()))].numpy()
+    return out
+
+
 def build_reference_model(mode: str):
     os.chdir(REF)
     import cvnets
@@ -162,6 +175,8 @@ def run_case(name, mode, batch, res, outdir):
               "layer_3.1.fusion.block.norm.running_mean", "layer_3.1.fusion.block.norm.running_var",
               "conv_1x1_exp.block.norm.running_var"):
         out["bn::" + k] = ref_sd_after[k].numpy()
+    if batch >= 16:
+        out.update(grad_sample_fields(ref_grads))
     for k, t in taps.items():
         out["tap_stats::" + k] = np.array([t.mean().item(), t.std().item(), t.abs().max().item()], dtype=np.float64)
         out["tap_slice::" + k] = t[0, : min(8, t.shape[1]), : min(4, t.shape[2]), : min(4, t.shape[3])].numpy()
@@ -250,6 +265,8 @@ def run_vit_case(name, mode, batch, res, outdir):
         out["grad::" + k] = ref_grads[k].numpy()
     for k in ("patch_emb.0.block.norm.running_mean", "patch_emb.1.block.norm.running_var"):
         out["bn::" + k] = ref_sd_after[k].numpy()
+    if batch >= 16:
+        out.update(grad_sample_fields(ref_grads))
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
     with open(os.path.join(outdir, f"vit_{mode}_keys.json"), "w") as f:
         json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
@@ -332,6 +349,8 @@ def run_v2_case(name, wm, batch, res, outdir):
         out["grad::" + k] = ref_grads[k].numpy()
     for k in ("conv_1.block.norm.running_mean", "layer_4.1.conv_proj.block.norm.running_var"):
         out["bn::" + k] = ref_sd_after[k].numpy()
+    if batch >= 16:
+        out.update(grad_sample_fields(ref_grads))
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
     with open(os.path.join(outdir, f"mobilevitv2_w{int(round(wm * 100)):03d}_keys.json"), "w") as f:
         json.dump({k: list(s) for k, s in shapes.items()}, f, indent=0)
@@ -464,10 +483,22 @@ def mha_cases(outdir):
     np.savez_compressed(os.path.join(outdir, "mha_cases.npz"), **out)
 
 
+LARGE_CASES = [("mobilevit_s_256_b16", "small", 16, 256)]        # the BASELINE configuration at a batch where train-mode BatchNorm noise is small
+LARGE_VIT_CASES = [("vit_tiny_224_b16", "tiny", 16, 224)]
+LARGE_V2_CASES = [("mobilevitv2_w100_256_b16", 1.0, 16, 256)]
+
 if __name__ == "__main__":
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     torch.set_num_threads(8)
+    if "--large" in sys.argv:  # large-batch bf16 parity fixtures only (tests/test_bf16_parity_gpu.py)
+        for c in LARGE_CASES:
+            run_case(*c, outdir)
+        for c in LARGE_VIT_CASES:
+            run_vit_case(*c, outdir)
+        for c in LARGE_V2_CASES:
+            run_v2_case(*c, outdir)
+        sys.exit(0)
     mha_cases(outdir)
     for c in CASES:
         run_case(*c, outdir)

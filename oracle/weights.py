@@ -57,3 +57,11 @@ def seeded_caption_tokens(batch: int, ctx: int, vocab: int, seed: int) -> torch.
         tok[b, e] = vocab - 1
         tok[b, e + 1:] = 0
     return torch.from_numpy(tok.astype(np.int64))
+
+
+def sample_indices(name: str, numel: int, n: int = 512) -> np.ndarray:
+    """deterministic subset of a tensor's flat indices (large-batch fixtures store gradients only at these positions)"""
+    if numel <= n:
+        return np.arange(numel, dtype=np.int64)
+    rng = np.random.Generator(np.random.PCG64([7, zlib.crc32(name.encode())]))
+    return np.sort(rng.choice(numel, size=n, replace=False)).astype(np.int64)

@@ -37,6 +37,12 @@ extern "C" {
  * memory-format conversion of model.to(memory_format=channels_last), main_train.py:72-79. */
 int cvh_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cp, void* stream);
 int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cs, void* stream);
+/* Device-side input stage: RandomMixup / RandomCutmix (data/transforms/image_torch.py:100-140, 290-336, applied at
+ * engine/training_engine.py:238) fused with the layout / dtype conversion above.  in = NCHW float32 batch; outside the box
+ * out[b] = lam*in[b] + (1-lam)*in[(b-1) mod B], inside [y1,y2) x [x1,x2) out[b] = in[(b-1) mod B] (mixup: empty box; cutmix: lam = 1).
+ * Cp > 0: out is NHWC `dtype` with channels zero-padded to Cp;  Cp == 0: out is NCHW float32 (the reference's own output format). */
+int cvh_mix_batch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cp, float lam, int x1, int y1, int x2, int y2,
+                  void* stream);
 /* Parameter packing (float32 torch layout [Cout][Cin][KH][KW] -> `dtype`).  mode 0: forward pack
  * [Cout][KH*KW][pad8(Cin)];  mode 1: dX pack (transposed, taps flipped) [Cin][KH*KW][pad8(Cout)];
  * mode 2: depthwise [KH*KW][C];  mode 3: patch-dX pack [KH*KW][pad8(Cin)][pad8(Cout)] (kernel == stride convs).  Replaces autocast's per-call weight cast (engine/utils.py:19-36). */
@@ -189,6 +195,11 @@ int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, void
 /* Dropout cvnets/layers/dropout.py:11-29: counter-based mask = f(*seed, stream_id, element index) */
 int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned int stream_id,
                 void* stream);
+/* StochasticDepth, torchvision "row" mode (cvnets/layers/stochastic_depth.py:10-18; cvnets/modules/transformer.py:140-155):
+ * y[r] = res[r] + x[r] * keep(sample(r)) / (1-p), one Bernoulli(1-p) draw per sample; sample(r) follows the unfold map of cvh_attn_*
+ * (ph, pw, H, W; ph = pw = H = 1, W = S: contiguous sequences of S tokens).  res == NULL: y = x * keep (also the backward). */
+int cvh_drop_path(int dtype, const void* x, const void* res, void* y, long long rows, int C, int ph, int pw, int H, int W, float p,
+                  const unsigned long long* seed, unsigned int stream_id, void* stream);
 int cvh_seed_advance(unsigned long long* seed, void* stream);
 int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void* stream);
 
@@ -242,6 +253,13 @@ int cvh_ce_fwd(int dtype, const void* logits, const long long* labels, float lab
                float* lse, int N, int M, void* stream);
 int cvh_ce_bwd(int dtype, const void* logits, const long long* labels, const float* lse, const float* gout, float label_smoothing,
                long long ignore_index, void* dlogits, int N, int M, void* stream);
+
+/* the same loss for PROBABILITY targets target[N][M] (float32; the mixtures RandomMixup / RandomCutmix produce): per row
+ * sum_j t'_ij (lse_i - z_ij) with t' = (1-eps) t + eps/M; tsum[N] = sum_j t'_ij is saved for bwd; mean over all rows is the caller's. */
+int cvh_ce_soft_fwd(int dtype, const void* logits, const float* target, float label_smoothing, float* loss_rows, float* lse, float* tsum, int N,
+                    int M, void* stream);
+int cvh_ce_soft_bwd(int dtype, const void* logits, const float* target, const float* lse, const float* tsum, const float* gout,
+                    float label_smoothing, void* dlogits, int N, int M, void* stream);
 
 /* ---- MobileViTv2: GroupNorm(1) ("layer_norm_2d") and linear self-attention ------------------------------ */
 /* LayerNorm2D_NCHW = nn.GroupNorm(num_groups=1) (cvnets/layers/normalization/layer_norm.py:75-108) on an NHWC map [B][HW][C]:

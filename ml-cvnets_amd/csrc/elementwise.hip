@@ -135,6 +135,95 @@ __global__ void weight_pack_multi_kernel(const long long* __restrict__ table, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side input stage: RandomMixup / RandomCutmix of data/transforms/image_torch.py (applied at
+// engine/training_engine.py:238) fused with the NCHW float32 -> NHWC `T` conversion of the model's first op.
+//   outside the box: out[b] = lam * x[b] + (1 - lam) * x[(b - 1) mod B]      (mixup: the box is empty; cutmix: lam = 1)
+//   inside  the box [y1, y2) x [x1, x2):  out[b] = x[(b - 1) mod B]           (cutmix paste from the batch rolled by one)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void mix_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int H, int W, int Cp, float lam, int x1, int y1,
+                                   int x2, int y2) {
+  const size_t npix = (size_t)B * H * W;
+  const int cgs = Cp / 8;
+  const size_t total = npix * cgs;
+  const size_t hw = (size_t)H * W;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = idx % npix;
+    const int cg = (int)(idx / npix);
+    const size_t b = pix / hw, rem = pix - b * hw;
+    const size_t br = (b + B - 1) % B;
+    const int h = (int)(rem / W), w = (int)(rem - (size_t)h * W);
+    const bool inside = h >= y1 && h < y2 && w >= x1 && w < x2;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      float v = 0.f;
+      if (c < C) {
+        const float a = in[(b * C + c) * hw + rem], r = in[(br * C + c) * hw + rem];
+        v = inside ? r : (lam * a + (1.f - lam) * r);
+      }
+      f[j] = v;
+    }
+    V8<T> v;
+    v8_pack(f, v);
+    v8_store<T>(out + pix * Cp + cg * 8, v);
+  }
+}
+// same mix, NCHW float32 -> NCHW float32 (the reference's own output format, for callers that keep their model-side conversion)
+__global__ void mix_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W, float lam, int x1, int y1, int x2,
+                                int y2) {
+  const size_t hw = (size_t)H * W, chw = (size_t)C * hw, total = (size_t)B * chw;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = idx / chw, rem = idx - b * chw;
+    const size_t p = rem % hw;
+    const int h = (int)(p / W), w = (int)(p - (size_t)h * W);
+    const float a = in[idx], r = in[((b + B - 1) % B) * chw + rem];
+    out[idx] = (h >= y1 && h < y2 && w >= x1 && w < x2) ? r : (lam * a + (1.f - lam) * r);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// StochasticDepth, torchvision "row" mode (cvnets/layers/stochastic_depth.py:10-18): y = res + x * keep(sample) / (1 - p), one
+// Bernoulli(1 - p) draw per SAMPLE of the block input.  Rows are tokens; the sample of a row follows the unfold map of cvh_attn_*
+// (nseq sequences of S tokens: a MobileViT block sees B*ph*pw samples), ph = pw = 1, H = 1, W = n_w = S is the contiguous case.
+// res == nullptr: y = x * keep (also the backward: dx = dy * keep with the same seed / stream id).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void drop_path_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, size_t rows, int C,
+                                                        int ph, int pw, int H, int W, float p, const unsigned long long* __restrict__ seed_p,
+                                                        unsigned int stream_id) {
+  const unsigned long long seed = *seed_p;
+  const float inv_keep = 1.0f / (1.0f - p);
+  const int cgs = C / 8;
+  const size_t total = rows * cgs;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = idx / cgs;
+    const int cg = (int)(idx - r * cgs);
+    // row -> (b, h, w) -> sample b * ph * pw + (h % ph) * pw + (w % pw)
+    const size_t hw = (size_t)H * W;
+    const size_t b = r / hw, rem = r - b * hw;
+    const int h = (int)(rem / W), w = (int)(rem - (size_t)h * W);
+    const size_t sample = b * ph * pw + (size_t)(h % ph) * pw + (w % pw);
+    const float k = dropout_scale(seed, stream_id, sample, p, inv_keep);
+    float f[8];
+    v8_unpack(v8_load<T>(x + r * C + cg * 8), f);
+    if (res != nullptr) {
+      float q[8];
+      v8_unpack(v8_load<T>(res + r * C + cg * 8), q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = q[j] + f[j] * k;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= k;
+    }
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(y + r * C + cg * 8, o);
+  }
+}
+
 // f32 vector -> T (bias etc.), or T -> f32
 template <typename T>
 __global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
@@ -721,6 +810,30 @@ extern "C" int cvh_nchw_to_nhwc(int dtype, const float* in, void* out, int B, in
 extern "C" int cvh_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int C, int H, int W, int Cs, void* stream) {
   size_t total = (size_t)B * C * H * W;
   DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)in, out, B, C, H, W, Cs);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_mix_batch(int dtype, const float* in, void* out, int B, int C, int H, int W, int Cp, float lam, int x1, int y1, int x2, int y2,
+                             void* stream) {
+  if (B <= 0) return 0;
+  if (Cp == 0) {  // NCHW float32 output
+    size_t total = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(mix_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, (float*)out, B, C, H, W, lam, x1, y1, x2, y2);
+    CVH_CHECK_LAUNCH();
+    return 0;
+  }
+  if (Cp % 8 || Cp < C) return -2;
+  size_t total = (size_t)B * H * W * (Cp / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((mix_to_nhwc_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, (T*)out, B, C, H, W, Cp, lam, x1, y1, x2, y2);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_drop_path(int dtype, const void* x, const void* res, void* y, long long rows, int C, int ph, int pw, int H, int W, float p,
+                             const unsigned long long* seed, unsigned int stream_id, void* stream) {
+  if (C % 8 || C <= 0 || p < 0.f || p >= 1.f || ph <= 0 || pw <= 0 || H <= 0 || W <= 0) return -2;
+  if (rows <= 0) return 0;
+  size_t total = (size_t)rows * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((drop_path_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res, (T*)y, (size_t)rows, C, ph, pw, H, W, p, seed, stream_id);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -285,6 +285,57 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
   }
 }
 
+// Probability targets (the [N][M] mixtures RandomMixup / RandomCutmix produce, data/transforms/image_torch.py:131-140): F.cross_entropy with
+// class probabilities and label smoothing = sum_j t'_ij (lse_i - z_ij), t' = (1-eps) t + eps/M; mean over ALL rows (no ignore_index).
+template <typename T>
+__global__ __launch_bounds__(256) void ce_soft_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target, float eps, float* __restrict__ loss_rows,
+                                                          float* __restrict__ lse, float* __restrict__ tsum, int N, int M) {
+  __shared__ float scr[16];
+  const int i = blockIdx.x;
+  const T* row = logits + (size_t)i * M;
+  const float* trow = target + (size_t)i * M;
+  float mx = -INFINITY, sm = 0.f, ts = 0.f, tz = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const float z = to_f<T>(row[j]), t = trow[j];
+    mx = fmaxf(mx, z);
+    sm += z;
+    ts += t;
+    tz += t * z;
+  }
+  mx = wave_max(mx); sm = wave_sum(sm); ts = wave_sum(ts); tz = wave_sum(tz);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { scr[wv] = mx; scr[4 + wv] = sm; scr[8 + wv] = ts; scr[12 + wv] = tz; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
+  sm = (scr[4] + scr[5]) + (scr[6] + scr[7]);
+  ts = (scr[8] + scr[9]) + (scr[10] + scr[11]);
+  tz = (scr[12] + scr[13]) + (scr[14] + scr[15]);
+  __syncthreads();
+  float ex = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) ex += __expf(to_f<T>(row[j]) - mx);
+  ex = wave_sum(ex);
+  if ((threadIdx.x & 63) == 0) scr[wv] = ex;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l = mx + __logf((scr[0] + scr[1]) + (scr[2] + scr[3]));
+    const float w = (1.f - eps) * ts + eps;  // sum_j t'_ij
+    lse[i] = l;
+    tsum[i] = w;
+    loss_rows[i] = w * l - (1.f - eps) * tz - eps * sm / (float)M;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_soft_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target, const float* __restrict__ lse,
+                                                          const float* __restrict__ tsum, const float* __restrict__ gout, float eps, T* __restrict__ dlogits,
+                                                          int N, int M) {
+  const int i = blockIdx.x;
+  const float l = lse[i], w = tsum[i], g = *gout, u = eps / (float)M;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const float p = __expf(to_f<T>(logits[(size_t)i * M + j]) - l);
+    dlogits[(size_t)i * M + j] = from_f<T>(g * (p * w - (1.f - eps) * target[(size_t)i * M + j] - u));
+  }
+}
+
 static inline int tk_grid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
@@ -384,6 +435,20 @@ extern "C" int cvh_ce_bwd(int dtype, const void* logits, const long long* labels
                           long long ignore_index, void* dlogits, int N, int M, void* stream) {
   if (N <= 0 || M <= 0) return -2;
   TK_DISPATCH(dtype, hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, labels, lse, gout, label_smoothing, ignore_index, (T*)dlogits, N, M);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_ce_soft_fwd(int dtype, const void* logits, const float* target, float label_smoothing, float* loss_rows, float* lse, float* tsum,
+                               int N, int M, void* stream) {
+  if (N <= 0 || M <= 0) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((ce_soft_fwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, target, label_smoothing, loss_rows, lse, tsum, N, M);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_ce_soft_bwd(int dtype, const void* logits, const float* target, const float* lse, const float* tsum, const float* gout,
+                               float label_smoothing, void* dlogits, int N, int M, void* stream) {
+  if (N <= 0 || M <= 0) return -2;
+  TK_DISPATCH(dtype, hipLaunchKernelGGL((ce_soft_bwd_kernel<T>), dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)logits, target, lse, tsum, gout, label_smoothing, (T*)dlogits, N, M);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -53,6 +53,8 @@ SIGNATURES = {
     "cvh_pool_bwd": [I, P, P, I, I, I, P],
     "cvh_dropout": [I, P, P, L, F, P, U, P],
     "cvh_seed_advance": [P, P],
+    "cvh_drop_path": [I, P, P, P, L, I, I, I, I, I, F, P, U, P],
+    "cvh_mix_batch": [I, P, P, I, I, I, I, I, F, I, I, I, I, P],
     "cvh_add": [I, P, P, P, L, P],
     "cvh_rows_gather_idx": [I, P, P, P, I, I, I, P],
     "cvh_l2norm_fwd": [I, P, P, P, I, I, F, P],
@@ -65,6 +67,8 @@ SIGNATURES = {
     "cvh_lerp_multi": [P, I, L, F, P],
     "cvh_ce_fwd": [I, P, P, F, L, P, P, I, I, P],
     "cvh_ce_bwd": [I, P, P, P, P, F, L, P, I, I, P],
+    "cvh_ce_soft_fwd": [I, P, P, F, P, P, P, I, I, P],
+    "cvh_ce_soft_bwd": [I, P, P, P, P, P, F, P, I, I, P],
     "cvh_gn_chunks": [I, I, I],
     "cvh_gn_fwd": [I, P, P, P, P, P, P, I, I, I, F, P],
     "cvh_gn_bwd": [I, P, P, P, P, P, P, P, I, I, I, P],

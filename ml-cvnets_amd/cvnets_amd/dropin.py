@@ -48,6 +48,7 @@ _BY_NAME = {
     "CLIP": clip.CLIP,
     # parameter-free leaves: swapped too, so that a swapped model holds no reference class at all (it can then be pickled / deep-copied /
     # shipped to a process that does not have the reference tree, and `act_code` sees the mirrors' own types)
+    "StochasticDepth": layers.StochasticDepth,
     "Swish": layers.Swish,
     "GELU": layers.GELU,
     "Identity": layers.Identity,

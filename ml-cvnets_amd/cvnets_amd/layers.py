@@ -339,6 +339,37 @@ class Dropout(nn.Dropout):
         return ops.dropout(x, self.p, self.training)
 
 
+class StochasticDepth(nn.Module):
+    """cvnets/layers/stochastic_depth.py:10-18 (torchvision.ops.StochasticDepth): per-sample Bernoulli(1 - p) / (1 - p) scaling; samples run
+    along dim 0.  TransformerEncoder fuses it with its residual add (ops.drop_path on the token matrix); this forward is the standalone
+    layer for [B, ...] tensors."""
+
+    def __init__(self, p: float, mode: str = "row") -> None:
+        super().__init__()
+        if mode != "row":
+            raise NotImplementedError('only mode="row" (the one the reference constructs) is on the HIP hot path')
+        self.p, self.mode = float(p), mode
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not self.training or self.p <= 0.0:
+            return x
+        B = x.shape[0]
+        if x.dim() == 4:  # feature map: NHWC rows, one sample = H*W consecutive rows
+            x = ops.to_nhwc(x)
+            _, C, H, W = x.shape
+            y = ops.drop_path(ops.tokens_of(x), None, self.p, True, (B, H * W, 1, 1, H * W, 1, H * W))
+            return ops.fmap_of(y, B, H, W)
+        C = x.shape[-1]
+        rows_per = x.numel() // (B * C)
+        x2 = x.reshape(B * rows_per, C)
+        if x2.dtype != ops.compute_dtype():
+            x2 = x2.to(ops.compute_dtype())
+        return ops.drop_path(x2.contiguous(), None, self.p, True, (B, rows_per, 1, 1, rows_per, 1, rows_per)).view(x.shape)
+
+    def __repr__(self) -> str:
+        return "{}(p={}, mode={})".format(self.__class__.__name__, self.p, self.mode)
+
+
 class GlobalPool(nn.Module):
     pool_types = ["mean", "rms", "abs"]
 

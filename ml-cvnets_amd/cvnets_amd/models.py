@@ -42,6 +42,80 @@ def get_configuration(opts) -> Dict:
     return cfg
 
 
+def _init_encoder_common(self, opts, kwargs) -> None:
+    """BaseImageEncoder.__init__ (base_image_encoder.py:36-47): dilation bookkeeping for dense-prediction heads + checkpoint flag"""
+    self.dilation = 1
+    output_stride = kwargs.get("output_stride", None)
+    self.dilate_l4 = self.dilate_l5 = False
+    if output_stride == 8:
+        self.dilate_l4 = self.dilate_l5 = True
+    elif output_stride == 16:
+        self.dilate_l5 = True
+    self.output_stride = output_stride
+    self.model_conf_dict = dict()
+    self.neural_augmentor = None
+    self.gradient_checkpointing = opt(opts, "model.classification.gradient_checkpointing", False)
+
+
+def _forward_layer(self, layer, x):
+    """base_image_encoder.py:196-204"""
+    if self.training and getattr(self, "gradient_checkpointing", False):
+        return ops.checkpoint(layer, x)
+    return layer(x)
+
+
+def _encoder_prologue(self, x):
+    ops.pack_all(self)  # every conv / linear weight packed by one launch for this forward (train AND eval: the fused optimizer / EMA
+    #                     kernels rewrite parameters through raw pointers, a cached pack could be stale)
+    if self.training:
+        ops.advance_dropout_seed(x.device)
+        ops.bump_bn_counters(self)
+    return ops.to_nhwc(x)
+
+
+def _extract_end_points_all(self, x: Tensor, use_l5: Optional[bool] = True, use_l5_exp: Optional[bool] = False, *args, **kwargs) -> Dict[str, Tensor]:
+    """base_image_encoder.py:206-254: the feature maps the segmentation / detection heads consume (out_l1 .. out_l5, out_l5_exp)"""
+    if getattr(self, "neural_augmentor", None) is not None and self.training:
+        raise NotImplementedError("neural augmentation is not on the HIP hot path")
+    out_dict = {}
+    x = _encoder_prologue(self, x)
+    try:
+        x = _forward_layer(self, self.conv_1, x)
+        x = _forward_layer(self, self.layer_1, x)
+        out_dict["out_l1"] = x
+        x = _forward_layer(self, self.layer_2, x)
+        out_dict["out_l2"] = x
+        x = _forward_layer(self, self.layer_3, x)
+        out_dict["out_l3"] = x
+        x = _forward_layer(self, self.layer_4, x)
+        out_dict["out_l4"] = x
+        if use_l5:
+            x = _forward_layer(self, self.layer_5, x)
+            out_dict["out_l5"] = x
+            if use_l5_exp:
+                x = _forward_layer(self, self.conv_1x1_exp, x)
+                out_dict["out_l5_exp"] = x
+        return out_dict
+    finally:
+        ops.end_bn_counters()
+
+
+def _extract_end_points_l4(self, x: Tensor, *args, **kwargs) -> Dict[str, Tensor]:
+    """base_image_encoder.py:256-259"""
+    return _extract_end_points_all(self, x, use_l5=False)
+
+
+def _extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
+    """base_image_encoder.py:261-275"""
+    x = _encoder_prologue(self, x)
+    try:
+        for name in ("conv_1", "layer_1", "layer_2", "layer_3", "layer_4", "layer_5", "conv_1x1_exp"):
+            x = _forward_layer(self, getattr(self, name), x)
+        return x
+    finally:
+        ops.end_bn_counters()
+
+
 class MobileViT(nn.Module):
     def __init__(self, opts, *args, **kwargs) -> None:
         super().__init__()
@@ -49,13 +123,13 @@ class MobileViT(nn.Module):
         classifier_dropout = opt(opts, "model.classification.classifier_dropout", 0.0)
         pool_type = opt(opts, "model.layer.global_pool", "mean")
         cfg = get_configuration(opts)
-        self.dilation = 1
-        self.model_conf_dict = dict()
+        _init_encoder_common(self, opts, kwargs)
         self.conv_1 = ConvLayer2d(opts=opts, in_channels=3, out_channels=16, kernel_size=3, stride=2, use_norm=True, use_act=True)
         self.model_conf_dict["conv1"] = {"in": 3, "out": 16}
         in_channels = 16
         for idx in range(1, 6):
-            layer, out_channels = self._make_layer(opts=opts, input_channel=in_channels, cfg=cfg[f"layer{idx}"])
+            layer, out_channels = self._make_layer(opts=opts, input_channel=in_channels, cfg=cfg[f"layer{idx}"],
+                                                   dilate=(idx == 4 and self.dilate_l4) or (idx == 5 and self.dilate_l5))
             setattr(self, f"layer_{idx}", layer)
             self.model_conf_dict[f"layer{idx}"] = {"in": in_channels, "out": out_channels}
             in_channels = out_channels
@@ -70,9 +144,9 @@ class MobileViT(nn.Module):
         self.classifier.add_module(name="fc", module=LinearLayer(in_features=exp_channels, out_features=num_classes, bias=True))
         self.n_classes = num_classes
 
-    def _make_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+    def _make_layer(self, opts, input_channel, cfg: Dict, dilate: bool = False) -> Tuple[nn.Sequential, int]:
         if cfg.get("block_type", "mobilevit").lower() == "mobilevit":
-            return self._make_mit_layer(opts, input_channel, cfg)
+            return self._make_mit_layer(opts, input_channel, cfg, dilate=dilate)
         return self._make_mobilenet_layer(opts, input_channel, cfg)
 
     @staticmethod
@@ -86,11 +160,17 @@ class MobileViT(nn.Module):
             input_channel = output_channels
         return nn.Sequential(*block), input_channel
 
-    def _make_mit_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+    def _make_mit_layer(self, opts, input_channel, cfg: Dict, dilate: bool = False) -> Tuple[nn.Sequential, int]:
+        # mobilevit.py:225-256: segmentation backbones trade the stride of layer_4 / layer_5 for dilation (output_stride 16 / 8)
+        prev_dilation = self.dilation
         block = []
-        if cfg.get("stride", 1) == 2:
-            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=cfg.get("out_channels"), stride=2,
-                                          expand_ratio=cfg.get("mv_expand_ratio", 4), dilation=self.dilation))
+        stride = cfg.get("stride", 1)
+        if stride == 2:
+            if dilate:
+                self.dilation *= 2
+                stride = 1
+            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=cfg.get("out_channels"), stride=stride,
+                                          expand_ratio=cfg.get("mv_expand_ratio", 4), dilation=prev_dilation))
             input_channel = cfg.get("out_channels")
         head_dim = cfg.get("head_dim", 32)
         transformer_dim = cfg["transformer_channels"]
@@ -108,24 +188,10 @@ class MobileViT(nn.Module):
             conv_ksize=opt(opts, "model.classification.mit.conv_kernel_size", 3)))
         return nn.Sequential(*block), input_channel
 
-    # base_image_encoder.py:261-283
-    def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
-        ops.pack_all(self)  # every conv / linear weight packed by one launch for this forward (train AND eval: the fused optimizer / EMA
-        #                     kernels rewrite parameters through raw pointers, a cached pack could be stale)
-        if self.training:
-            ops.advance_dropout_seed(x.device)
-            ops.bump_bn_counters(self)
-        try:
-            x = ops.to_nhwc(x)
-            x = self.conv_1(x)
-            x = self.layer_1(x)
-            x = self.layer_2(x)
-            x = self.layer_3(x)
-            x = self.layer_4(x)
-            x = self.layer_5(x)
-            return self.conv_1x1_exp(x)
-        finally:
-            ops.end_bn_counters()
+    # base_image_encoder.py:196-283
+    extract_end_points_all = _extract_end_points_all
+    extract_end_points_l4 = _extract_end_points_l4
+    extract_features = _extract_features
 
     def forward_classifier(self, x: Tensor, *args, **kwargs) -> Tensor:
         x = self.extract_features(x)
@@ -181,12 +247,17 @@ class VisionTransformer(nn.Module):
             ConvLayer2d(opts=opts, in_channels=stem_dim, out_channels=stem_dim, kernel_size=2, stride=2, bias=False, use_norm=True, use_act=True),
             ConvLayer2d(opts=opts, in_channels=stem_dim, out_channels=embed_dim, kernel_size=2, stride=2, bias=True, use_norm=False, use_act=False),
         )
-        if opt(opts, "model.classification.vit.stochastic_dropout", 0.0) > 0.0:
-            raise NotImplementedError("StochasticDepth is not on the HIP hot path")
+        n_layers = cfg["n_transformer_layers"]
+        sd_max = opt(opts, "model.classification.vit.stochastic_dropout", 0.0)
+        # vit.py:126-132: the drop rate grows linearly with depth (np.linspace, rounded to 3 decimals)
+        sd_rates = [round(sd_max * i / max(n_layers - 1, 1), 3) for i in range(n_layers)]
         blocks = [TransformerEncoder(opts=opts, embed_dim=embed_dim, ffn_latent_dim=cfg["ffn_dim"], num_heads=cfg["n_attn_heads"],
                                      attn_dropout=cfg["attn_dropout"], dropout=cfg["dropout"], ffn_dropout=cfg["ffn_dropout"],
-                                     transformer_norm_layer=norm_layer, stochastic_dropout=0.0)
-                  for _ in range(cfg["n_transformer_layers"])]
+                                     transformer_norm_layer=norm_layer, stochastic_dropout=sd_rates[i])
+                  for i in range(n_layers)]
+        # base_image_encoder.py:36-47 / vit.py:150-165: activation checkpointing over `checkpoint_segments` chunks of the encoder stack
+        self.gradient_checkpointing = opt(opts, "model.classification.gradient_checkpointing", False)
+        self.checkpoint_segments = opt(opts, "model.classification.vit.checkpoint_segments", 4)
         self.post_transformer_norm = get_normalization_layer(opts=opts, num_features=embed_dim, norm_type=norm_layer)
         self.transformer = nn.Sequential(*blocks)
         self.classifier = LinearLayer(embed_dim, num_classes)
@@ -224,8 +295,22 @@ class VisionTransformer(nn.Module):
             raise NotImplementedError("return_image_embeddings (dense-prediction heads) is not on the HIP hot path")
         t, B, S, _ = self.extract_patch_embeddings(x)
         seqmap = (B, S, 1, 1, S, 1, S)
-        for layer in self.transformer:
-            t = layer.forward_tokens(t, seqmap)
+        layers = list(self.transformer)
+        if self.training and getattr(self, "gradient_checkpointing", False):
+            # vit.py:525-533 (checkpoint_sequential): the stack is cut into `checkpoint_segments` chunks; only chunk inputs are kept
+            nseg = max(1, min(int(getattr(self, "checkpoint_segments", 4)), len(layers)))
+            per = (len(layers) + nseg - 1) // nseg
+            for i in range(0, len(layers), per):
+                chunk = layers[i:i + per]
+
+                def run(tt, chunk=chunk):
+                    for layer in chunk:
+                        tt = layer.forward_tokens(tt, seqmap)
+                    return tt
+                t = ops.checkpoint(run, t)
+        else:
+            for layer in layers:
+                t = layer.forward_tokens(t, seqmap)
         n = self.post_transformer_norm
         t = ops.layer_norm_tokens(t, n, seqmap)
         if self.cls_token is None:
@@ -280,14 +365,14 @@ class MobileViTv2(nn.Module):
         pool_type = opt(opts, "model.layer.global_pool", "mean")
         cfg = get_mitv2_configuration(opts)
         image_channels, out_channels = cfg["layer0"]["img_channels"], cfg["layer0"]["out_channels"]
-        self.dilation = 1
-        self.model_conf_dict = dict()
+        _init_encoder_common(self, opts, kwargs)
         self.conv_1 = ConvLayer2d(opts=opts, in_channels=image_channels, out_channels=out_channels, kernel_size=3, stride=2, use_norm=True,
                                   use_act=True)
         self.model_conf_dict["conv1"] = {"in": image_channels, "out": out_channels}
         in_channels = out_channels
         for idx in range(1, 6):
-            layer, out_channels = self._make_layer(opts=opts, input_channel=in_channels, cfg=cfg[f"layer{idx}"])
+            layer, out_channels = self._make_layer(opts=opts, input_channel=in_channels, cfg=cfg[f"layer{idx}"],
+                                                   dilate=(idx == 4 and self.dilate_l4) or (idx == 5 and self.dilate_l5))
             setattr(self, f"layer_{idx}", layer)
             self.model_conf_dict[f"layer{idx}"] = {"in": in_channels, "out": out_channels}
             in_channels = out_channels
@@ -299,16 +384,21 @@ class MobileViTv2(nn.Module):
                                         LinearLayer(in_features=out_channels, out_features=num_classes, bias=True))
         self.n_classes = num_classes
 
-    def _make_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+    def _make_layer(self, opts, input_channel, cfg: Dict, dilate: bool = False) -> Tuple[nn.Sequential, int]:
         if cfg.get("block_type", "mobilevit").lower() == "mobilevit":
-            return self._make_mit_layer(opts, input_channel, cfg)
+            return self._make_mit_layer(opts, input_channel, cfg, dilate=dilate)
         return MobileViT._make_mobilenet_layer(opts, input_channel, cfg)
 
-    def _make_mit_layer(self, opts, input_channel, cfg: Dict) -> Tuple[nn.Sequential, int]:
+    def _make_mit_layer(self, opts, input_channel, cfg: Dict, dilate: bool = False) -> Tuple[nn.Sequential, int]:
+        prev_dilation = self.dilation  # mobilevit_v2.py:165-190: stride traded for dilation (output_stride 16 / 8)
         block = []
-        if cfg.get("stride", 1) == 2:
-            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=cfg.get("out_channels"), stride=2,
-                                          expand_ratio=cfg.get("mv_expand_ratio", 4), dilation=self.dilation))
+        stride = cfg.get("stride", 1)
+        if stride == 2:
+            if dilate:
+                self.dilation *= 2
+                stride = 1
+            block.append(InvertedResidual(opts=opts, in_channels=input_channel, out_channels=cfg.get("out_channels"), stride=stride,
+                                          expand_ratio=cfg.get("mv_expand_ratio", 4), dilation=prev_dilation))
             input_channel = cfg.get("out_channels")
         block.append(MobileViTBlockv2(
             opts=opts, in_channels=input_channel, attn_unit_dim=cfg["attn_unit_dim"], ffn_multiplier=cfg.get("ffn_multiplier"),
@@ -318,19 +408,9 @@ class MobileViTv2(nn.Module):
             attn_norm_layer=opt(opts, "model.classification.mitv2.attn_norm_layer", "layer_norm_2d"), dilation=self.dilation))
         return nn.Sequential(*block), input_channel
 
-    def extract_features(self, x: Tensor, *args, **kwargs) -> Tensor:
-        ops.pack_all(self)  # train AND eval (see MobileViT.extract_features)
-        if self.training:
-            ops.advance_dropout_seed(x.device)
-            ops.bump_bn_counters(self)
-        try:
-            x = ops.to_nhwc(x)
-            x = self.conv_1(x)
-            for idx in range(1, 6):
-                x = getattr(self, f"layer_{idx}")(x)
-            return self.conv_1x1_exp(x)
-        finally:
-            ops.end_bn_counters()
+    extract_end_points_all = _extract_end_points_all
+    extract_end_points_l4 = _extract_end_points_l4
+    extract_features = _extract_features
 
     def forward_classifier(self, x: Tensor, *args, **kwargs) -> Tensor:
         return self.classifier(self.extract_features(x))

@@ -11,7 +11,7 @@ import torch
 from torch import Tensor, nn
 
 from . import fused, ops
-from .layers import (ConvLayer2d, Dropout, Identity, LayerNorm, LinearLayer, LinearSelfAttention, MultiHeadAttention, act_code,
+from .layers import (ConvLayer2d, Dropout, Identity, LayerNorm, LinearLayer, LinearSelfAttention, MultiHeadAttention, StochasticDepth, act_code,
                      build_activation_layer, get_normalization_layer, opt)
 
 
@@ -127,7 +127,10 @@ class TransformerEncoder(nn.Module):
         )
         self.drop_path = Identity()
         if stochastic_dropout > 0.0:
-            raise NotImplementedError("StochasticDepth is not on the HIP hot path (reference MobileViT/ViT YAMLs use 0.0)")
+            if dropout > 0.0:  # transformer.py:108-112: the reference refuses this combination as well
+                raise ValueError("Stochastic dropout and dropout are mutually exclusive. Use either of them, but not both."
+                                 " Got: {} and {}".format(stochastic_dropout, dropout))
+            self.drop_path = StochasticDepth(p=stochastic_dropout, mode="row")
         self.embed_dim = embed_dim
         self.ffn_dim = ffn_latent_dim
         self.ffn_dropout = ffn_dropout
@@ -151,6 +154,15 @@ class TransformerEncoder(nn.Module):
         p2 = drop2.p if self.training else 0.0
         if drop_ffn.p > 0.0 and self.training:
             raise NotImplementedError("ffn_dropout > 0 is not fused (reference YAMLs use 0.0)")
+        sd = self.drop_path.p if (self.training and isinstance(self.drop_path, StochasticDepth)) else 0.0
+        if sd > 0.0:
+            # x = x + StochasticDepth(Dropout(branch(LN(x)))): one Bernoulli draw per sample scales the whole branch; the residual add rides in
+            # the drop-path kernel instead of the GEMM epilogue (transformer.py:140-155)
+            y = ops.layer_norm_tokens(x, ln1, seqmap)
+            x = ops.drop_path(mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1), x, sd, True, seqmap)
+            y = ops.layer_norm_tokens(x, ln2, seqmap)
+            h = ops.linear(ops.linear(y, fc1.weight, fc1.bias, act=act_code(act)), fc2.weight, fc2.bias, drop_p=p2)
+            return ops.drop_path(h, x, sd, True, seqmap)
         # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue
         y = ops.layer_norm_tokens(x, ln1, seqmap)
         x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x)

@@ -143,7 +143,19 @@ def nhwc_to_nchw_f32(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # dropout state: one device-resident 64-bit seed per device; masks are f(seed, stream_id, element)
 # ------------------------------------------------------------------------------------------------
-_stream_ids = itertools.count(1)
+class _Counter:
+    """dropout stream ids: one per op call, in call order (a plain counter whose position `checkpoint` can pin and restore)"""
+
+    def __init__(self, start: int = 1):
+        self.value = start
+
+    def __next__(self) -> int:
+        v = self.value
+        self.value += 1
+        return v
+
+
+_stream_ids = _Counter(1)
 _seeds = {}      # device index -> the generator state (advanced once per training forward)
 _seed_snap = {}  # device index -> snapshot of the state taken by the CURRENT forward
 
@@ -1253,7 +1265,34 @@ class CrossEntropyFn(torch.autograd.Function):
         return dlogits, None, None, None
 
 
+class SoftCrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits [N, M], class probabilities [N, M], label_smoothing): the targets RandomMixup / RandomCutmix produce"""
+
+    @staticmethod
+    def forward(ctx, logits, target, label_smoothing):
+        _check_dev(logits)
+        logits = logits.contiguous()
+        target = target.float().contiguous()  # plumbing
+        N, M = logits.shape
+        rows, lse, tsum = _f32(N, logits.device), _f32(N, logits.device), _f32(N, logits.device)
+        _lib.call("cvh_ce_soft_fwd", _dt(logits), _p(logits), _p(target), float(label_smoothing), _p(rows), _p(lse), _p(tsum), N, M, _stream())
+        ctx.save_for_backward(logits, target, lse, tsum)
+        ctx.eps = float(label_smoothing)
+        return rows.sum() / N  # plumbing: N-element reduction
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse, tsum = ctx.saved_tensors
+        N, M = logits.shape
+        gout = (g.float() / N).reshape(1)  # plumbing: scalar
+        dlogits = torch.empty_like(logits)
+        _lib.call("cvh_ce_soft_bwd", _dt(logits), _p(logits), _p(target), _p(lse), _p(tsum), _p(gout), ctx.eps, _p(dlogits), N, M, _stream())
+        return dlogits, None, None
+
+
 def cross_entropy(logits, labels, label_smoothing: float = 0.0, ignore_index: int = -1):
+    if labels.dim() == 2:  # class probabilities (mixup / cutmix)
+        return SoftCrossEntropyFn.apply(logits, labels, float(label_smoothing))
     return CrossEntropyFn.apply(logits, labels, float(label_smoothing), int(ignore_index))
 
 
@@ -1287,3 +1326,92 @@ def dropout(x, p: float, training: bool):
     if not training or p <= 0.0:
         return x
     return DropoutFn.apply(x, float(p), next_stream_id())
+
+
+# ------------------------------------------------------------------------------------------------
+# StochasticDepth ("row" mode) fused with the residual add
+# ------------------------------------------------------------------------------------------------
+class DropPathFn(torch.autograd.Function):
+    """y = res + x * keep(sample) / (1 - p)  (cvnets/layers/stochastic_depth.py:10-18 = torchvision StochasticDepth(mode="row") followed by
+    the residual add of cvnets/modules/transformer.py:140-155); the sample of a token row follows `seqmap` as in AttentionFn."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, stream_id, seqmap):
+        _check_dev(x)
+        nseq, S, ph, pw, n_w, H, W = seqmap
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        seed = dropout_seed(x.device)
+        _lib.call("cvh_drop_path", _dt(x), _p(x), _p(res), _p(y), rows, C, ph, pw, H, W, float(p), _p(seed), stream_id, _stream())
+        ctx.cfg = (float(p), stream_id, (ph, pw, H, W), res is not None)
+        ctx.seed = seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, stream_id, (ph, pw, H, W), has_res = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.call("cvh_drop_path", _dt(dy), _p(dy), None, _p(dx), dy.shape[0], dy.shape[1], ph, pw, H, W, p, _p(ctx.seed), stream_id, _stream())
+        return dx, (dy if has_res else None), None, None, None
+
+
+def drop_path(x2d, res, p: float, training: bool, seqmap):
+    """x2d / res: [rows, C] token matrices; returns res + StochasticDepth(x2d) (res may be None)"""
+    if not training or p <= 0.0:
+        return x2d if res is None else add(x2d, res)
+    return DropPathFn.apply(x2d, res, float(p), next_stream_id(), tuple(int(v) for v in seqmap))
+
+
+# ------------------------------------------------------------------------------------------------
+# activation checkpointing that keeps the counter-based dropout streams aligned
+# ------------------------------------------------------------------------------------------------
+def checkpoint(fn, *inputs):
+    """torch.utils.checkpoint (base_image_encoder.py:196-204, vit.py:533 `gradient_checkpoint_fn`) for HIP layers: dropout / drop-path
+    masks are functions of (per-forward seed snapshot, per-op stream id); the recomputation in backward must draw the SAME ids and read
+    the SAME snapshot as the original forward, so both are pinned around `fn`."""
+    import torch.utils.checkpoint as _cp
+
+    dev = next((t.device for t in inputs if isinstance(t, torch.Tensor)), None)
+    key = (dev.index or 0) if dev is not None and dev.type == "cuda" else None
+    start = _stream_ids.value                      # the ids fn's ops will take (nothing is consumed here: a checkpointed and a plain
+    snap = _seed_snap.get(key) if key is not None else None  # forward of the same model draw identical masks)
+
+    def run(*args):
+        saved_id, saved_snap = _stream_ids.value, (_seed_snap.get(key) if key is not None else None)
+        _stream_ids.value = start
+        if snap is not None:
+            _seed_snap[key] = snap
+        try:
+            out = fn(*args)
+        finally:
+            if snap is not None and saved_snap is not None:
+                _seed_snap[key] = saved_snap
+            # original forward: saved_id == start, continue after the ids consumed here; recomputation in backward: restore the caller's
+            _stream_ids.value = max(_stream_ids.value, saved_id)
+        return out
+
+    return _cp.checkpoint(run, *inputs, use_reentrant=False, preserve_rng_state=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side input stage: mixup / cutmix fused with the layout + dtype conversion
+# ------------------------------------------------------------------------------------------------
+def mix_batch(x: torch.Tensor, lam: float, box=None, *, to_nhwc_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """x: NCHW float32 batch on the GPU.  box = None: mixup, out[b] = lam*x[b] + (1-lam)*x[b-1];  box = (x1, y1, x2, y2): cutmix, the box is
+    pasted from x[b-1] (lam is ignored inside and 1 outside).  `to_nhwc_dtype` set: returns the NHWC compute-dtype tensor the models
+    consume (channels padded to 8) — mixing, layout change and cast in ONE pass; otherwise NCHW float32 like the reference."""
+    _check_dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()  # plumbing
+    B, C, H, W = x.shape
+    x1, y1, x2, y2 = (0, 0, 0, 0) if box is None else (int(v) for v in box)
+    lam_out = float(lam) if box is None else 1.0
+    if to_nhwc_dtype is not None:
+        Cp = pad8(C)
+        out = nhwc_empty(B, Cp, H, W, to_nhwc_dtype, x.device)
+        _lib.call("cvh_mix_batch", _dt(out), _p(x), _p(out), B, C, H, W, Cp, lam_out, x1, y1, x2, y2, _stream())
+        return out
+    out = torch.empty_like(x)
+    _lib.call("cvh_mix_batch", 0, _p(x), _p(out), B, C, H, W, 0, lam_out, x1, y1, x2, y2, _stream())
+    return out

@@ -483,6 +483,54 @@ def mha_cases(outdir):
     np.savez_compressed(os.path.join(outdir, "mha_cases.npz"), **out)
 
 
+
+def run_endpoints_case(outdir, name="mobilevit_s_os8_96_b2", mode="small", output_stride=8, batch=2, res=96):
+    """the backbone as the segmentation / detection heads use it — BaseImageEncoder.extract_end_points_all on a
+    MobileViT built with output_stride (layer_4 / layer_5 trade their stride for dilation, base_image_encoder.py:36-47, 206-259;
+    mobilevit.py:225-256).  The reference class is constructed directly with the kwarg the segmentation builder passes."""
+    torch.manual_seed(0)
+    build_reference_model(mode)  # sets cwd / sys.path and registers everything
+    import cvnets
+    from cvnets.models.classification.mobilevit import MobileViT as RefMobileViT
+    from options.utils import flatten_yaml_as_dict
+    parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+    opts = parser.parse_args([])
+    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/classification/imagenet/mobilevit.yaml")))
+    for k, v in cfg.items():
+        if hasattr(opts, k):
+            setattr(opts, k, v)
+    setattr(opts, "dataset.category", "classification")
+    setattr(opts, "dev.device", "cpu")
+    setattr(opts, "model.classification.mit.mode", mode)
+    for k in ("model.classification.mit.dropout", "model.classification.mit.attn_dropout", "model.classification.mit.ffn_dropout",
+              "model.classification.classifier_dropout"):
+        setattr(opts, k, 0.0)
+    model = RefMobileViT(opts, output_stride=output_stride)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)
+    x = seeded_input((batch, 3, res, res), seed=1)
+    model.train()
+    ep = model.extract_end_points_all(x, use_l5=True, use_l5_exp=True)
+    loss = sum(v.square().mean() for k, v in ep.items() if k.startswith("out_"))
+    model.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    names = list(grads.keys())
+    out = {"loss": np.float32(loss.item()), "grad_names": np.array(names),
+           "grad_norm": np.array([grads[k].norm().item() for k in names], dtype=np.float64),
+           "strides": np.array([model.layer_4[0].stride, model.layer_4[0].dilation, model.layer_5[0].stride, model.layer_5[0].dilation])}
+    for k, v in ep.items():
+        out["shape::" + k] = np.array(v.shape)
+        out["stats::" + k] = np.array([v.mean().item(), v.std().item(), v.abs().max().item()], dtype=np.float64)
+        if k in ("out_l4", "out_l5"):
+            out["full::" + k] = v.detach().numpy()
+    for k in ("layer_4.0.block.conv_3x3.block.conv.weight", "layer_5.0.block.conv_3x3.block.conv.weight", "layer_5.1.local_rep.conv_3x3.block.conv.weight",
+              "conv_1.block.conv.weight"):
+        out["grad::" + k] = grads[k].numpy()
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print(name, {k: tuple(v.shape) for k, v in ep.items()}, "loss", float(loss))
+
 LARGE_CASES = [("mobilevit_s_256_b16", "small", 16, 256)]        # the BASELINE configuration at a batch where train-mode BatchNorm noise is small
 LARGE_VIT_CASES = [("vit_tiny_224_b16", "tiny", 16, 224)]
 LARGE_V2_CASES = [("mobilevitv2_w100_256_b16", 1.0, 16, 256)]
@@ -491,6 +539,10 @@ if __name__ == "__main__":
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     torch.set_num_threads(8)
+    if "--endpoints" in sys.argv:
+        run_endpoints_case(outdir)
+        run_endpoints_case(outdir, name="mobilevit_xxs_os16_64_b2", mode="xx_small", output_stride=16, batch=2, res=64)
+        sys.exit(0)
     if "--large" in sys.argv:  # large-batch bf16 parity fixtures only (tests/test_bf16_parity_gpu.py)
         for c in LARGE_CASES:
             run_case(*c, outdir)

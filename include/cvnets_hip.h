@@ -76,6 +76,13 @@ int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, i
                 int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
                 int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream);
 long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot);
+/* cvh_gemm_dw that also emits the bias gradient of the same layer: bias_part[rows][N] (rows = cvh_gemm_dw_scratch_elems / (N*Ktot),
+ * requires scratch) receives the column sums of dY over each partial row's share of M; their sum over rows is db (cvh_reduce_multi,
+ * kind 0).  dY is read once for dW and db.  cvh_gemm_dw_folds_bias() == 0: the kernel this shape runs on cannot (use cvh_colsum). */
+int cvh_gemm_dw_bias(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw, float* bias_part,
+                     int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                     int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream);
+int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot);
 /* dX of a non-overlapping strided conv (kernel == stride, pad 0: ViT patch-embedding convs, cvnets/models/classification/vit.py:89-123):
  * dx[B][H][W][Cin] = scatter(dy[B*Ho*Wo][Cout] x wgt^T), wgt = mode-3 pack. */
 int cvh_conv_dx_patch(int dtype, const void* dy, const void* wgt, void* dx, int B, int Ho, int Wo, int Cout, int KH, int KW,

@@ -68,6 +68,61 @@ __global__ __launch_bounds__(256) void bn_dx_weights_kernel(const float* __restr
   }
 }
 
+// Same result with W, cb and cc staged in LDS by ONE coalesced pass (N * (K + 1) + 2 N floats must fit): the version above walks W with
+// dependent strided global loads, and on the backward critical path — between the depthwise backward kernel and the dX GEMM, while a dW
+// GEMM saturates HBM from the side stream — those loads took up to 750 us for a 16 KB weight.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_dx_weights_lds_kernel(const float* __restrict__ w, const float* __restrict__ coef, T* __restrict__ wcat,
+                                                                float* __restrict__ bias, int N, int K, int Kp) {
+  extern __shared__ float smem_f[];
+  __shared__ float red[256];
+  const int P = K + 1;
+  float* wl = smem_f;            // [N][K + 1]
+  float* cbl = wl + N * P;       // [N]
+  float* ccl = cbl + N;          // [N]
+  const int k = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < N * K; i += 256) {
+    const int n = i / K;
+    wl[n * P + (i - n * K)] = w[i];
+  }
+  for (int n = tid; n < N; n += 256) { cbl[n] = coef[N + n]; ccl[n] = coef[2 * N + n]; }
+  __syncthreads();
+  T* row = wcat + (size_t)k * (N + Kp);
+  const bool live = k < K;
+  for (int n = tid; n < N; n += 256) row[n] = from_f<T>(live ? coef[n] * wl[n * P + k] : 0.f);
+  const int JW = Kp <= 32 ? 32 : (Kp <= 64 ? 64 : 128);
+  const int NS = 256 / JW;
+  const int j = tid % JW, sl = tid / JW;
+  for (int j0 = 0; j0 < Kp; j0 += JW) {
+    const int jj = j0 + j;
+    float q = 0.f, b = 0.f;
+    if (live && jj < K) {
+      for (int n = sl; n < N; n += NS) q += cbl[n] * wl[n * P + k] * wl[n * P + jj];
+    }
+    if (live && j0 == 0 && j == 0) {
+      for (int n = sl; n < N; n += NS) b += ccl[n] * wl[n * P + k];
+    }
+    __syncthreads();
+    red[tid] = q;
+    __syncthreads();
+    if (sl == 0) {
+      float t = 0.f;
+      for (int s2 = 0; s2 < NS; ++s2) t += red[s2 * JW + j];
+      if (jj < Kp) row[N + jj] = from_f<T>(t);
+    }
+    if (j0 == 0) {
+      __syncthreads();
+      red[tid] = (j == 0) ? b : 0.f;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+        for (int s2 = 0; s2 < NS; ++s2) t += red[s2 * JW];
+        bias[k] = t;
+      }
+    }
+  }
+}
+
 // dw[n][k] = (accumulate ? dw : 0) + ca[n] * P[n][k] + cb[n] * sum_j w[n][j] * G[j][k] + cc[n] * s[k]
 // P = g^T x [N][K], G = x^T x [Kp][Kp], s = column sums of x [Kp]
 __global__ __launch_bounds__(256) void bn_dw_combine_kernel(const float* __restrict__ P, const float* __restrict__ w, const float* __restrict__ G,
@@ -86,6 +141,20 @@ extern "C" int cvh_bn_dx_weights(int dtype, const float* w, const float* coef, v
   if (N <= 0 || K <= 0 || (N % 8) != 0) return -2;
   const int Kp = (K + 7) / 8 * 8;
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds = ((size_t)N * (K + 1) + 2 * (size_t)N) * sizeof(float);
+  if (lds <= 96 * 1024 && (dtype == CVH_DT_BF16 || dtype == CVH_DT_F32)) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bn_dx_weights_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bn_dx_weights_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((bn_dx_weights_lds_kernel<bf16_t>), dim3(Kp), dim3(256), lds, st, w, coef, (bf16_t*)wcat, bias, N, K, Kp);
+    else hipLaunchKernelGGL((bn_dx_weights_lds_kernel<float>), dim3(Kp), dim3(256), lds, st, w, coef, (float*)wcat, bias, N, K, Kp);
+    CVH_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((bn_dx_weights_kernel<bf16_t>), dim3(Kp), dim3(256), 0, st, w, coef, (bf16_t*)wcat, bias, N, K, Kp);
   else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((bn_dx_weights_kernel<float>), dim3(Kp), dim3(256), 0, st, w, coef, (float*)wcat, bias, N, K, Kp);
   else return -1;

@@ -321,6 +321,8 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_DW_XCD 4        /* depthwise: XCD-contiguous block mapping on/off */
 #define CVH_TUNE_BIG_GEMM 5    /* 1: transformer-sized linears use the 128x128 direct-to-LDS kernel (gemm_big.hip), 0: conv_gemm */
 #define CVH_TUNE_COLRED_ROWS 6 /* cap on the number of partial rows (= workgroups) of the column-reduction kernels */
+#define CVH_TUNE_NO_SKINNY 9   /* 1: pointwise dW of small tiles stays on gemm_tn_kernel */
+#define CVH_TUNE_SKINNY_WGS 10 /* workgroups of gemm_tn_skinny_kernel (0: 512) */
 #define CVH_TUNE_MAX 16
 int cvh_tune_get(int key);
 

@@ -127,6 +127,15 @@ extern "C" int cvh_conv_dx_patch(int dtype, const void* dy, const void* wgt, voi
 
 static bool tn_big_shape(int M, int N, int Ktot) { return M >= 2048 && N >= 256 && (N % 128) == 0 && Ktot >= 256 && (Ktot % 128) == 0; }
 
+// one small output tile under millions of rows (gemm_tn.hpp: gemm_tn_skinny_kernel).  A property of the SHAPE alone, so that the scratch
+// size query needs no more than (M, N, Ktot): such problems always produce 4 partial rows per split; launches the skinny kernel cannot
+// take (fp32, im2col, two sources, operand transforms) run gemm_tn_kernel with four times the splits instead.
+static bool tn_skinny_shape(int M, int N, int Ktot) {
+  if (cvh_tune_get(CVH_TUNE_NO_SKINNY)) return false;
+  const int nt = (N + 31) / 32, kt = (Ktot + 31) / 32;
+  return M >= 32768 && N <= 128 && Ktot <= 64 && nt * kt <= 4;
+}
+
 static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* splits, int* mps) {
   const int n_tiles = (N + 127) / 128;
   *k_tiles = (Ktot + 127) / 128;
@@ -152,9 +161,15 @@ static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* s
     sp = (target_wgs + *out_tiles - 1) / *out_tiles;
   }
   int max_splits = (M + 255) / 256;
+  if (tn_skinny_shape(M, N, Ktot)) {  // gemm_tn_skinny_kernel: 4 partial rows per workgroup, >= 4 stages per wave
+    const int wgs = cvh_tune_get(CVH_TUNE_SKINNY_WGS) > 0 ? cvh_tune_get(CVH_TUNE_SKINNY_WGS) : 512;
+    sp = wgs;
+    max_splits = (M + 511) / 512;
+  }
   if (sp > max_splits) sp = max_splits;
   if (sp < 1) sp = 1;
   int m = (M + sp - 1) / sp;
+  if (tn_skinny_shape(M, N, Ktot)) m = ((m + 127) / 128) * 128;  // four interleaved 32-row stages
   m = ((m + 63) / 64) * 64;  // whole 64-row reduction steps (gemm_tn128_kernel); also a multiple of the 32-row step of gemm_tn_kernel
   *splits = (M + m - 1) / m;
   *mps = m;
@@ -186,8 +201,18 @@ extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
   if (M <= 0) return 0;
   int ot, kt, sp, mps;
   tn_plan(M, N, Ktot, &ot, &kt, &sp, &mps);
-  return (long long)sp * N * Ktot;
+  return (long long)sp * (tn_skinny_shape(M, N, Ktot) ? 4 : 1) * N * Ktot;
 }
+
+// 1 when cvh_gemm_dw_bias can emit the column sums of dY from the dW kernel it would pick (everything but the transformer-sized
+// direct-to-LDS kernel of gemm_big.hip, whose operands never pass through registers)
+extern "C" int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot) {
+  if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot)) return 0;
+  return M > 0 ? 1 : 0;
+}
+
+static int gemm_dw_finish(const GemmTNParams& p, int splits, int N, int KH, int KW, int C1, int C2, int Cin_real, float* dw, int accumulate,
+                          hipStream_t st);
 
 static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1, int C2, int Cin_real, float* dw, float* scratch,
                        long long scratch_elems, int accumulate, hipStream_t st, bool fx) {
@@ -198,13 +223,30 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
   // scratch path: every split writes its partial tile, one reduce kernel sums them (assign or accumulate into dw).
   // Without scratch: fp32 atomics into dw, which the caller must have zeroed (accumulate semantics only).
   p.part = nullptr;
+  const bool skinny_shape = tn_skinny_shape(p.M, N, p.Ktot);
+  const int rows = splits * (skinny_shape ? 4 : 1);
   if (scratch != nullptr) {
-    if (scratch_elems < (long long)splits * N * p.Ktot) return -2;
+    if (scratch_elems < (long long)rows * N * p.Ktot) return -2;
     p.part = scratch;
-  } else if (!accumulate) {
+  } else if (!accumulate || skinny_shape || p.bias_part != nullptr) {
     return -2;
   }
-  dim3 grid(out_tiles, splits);
+  const bool skinny = skinny_shape && !fx && dtype == CVH_DT_BF16 && KH * KW == 1 && p.stride == 1 && p.pad == 0 && C2 == 0;
+  if (skinny) {
+    const int nt = (N + 31) / 32, kt = (p.Ktot + 31) / 32;
+    const dim3 g(splits), b(256);
+#define SKINNY(NT_, KT_, PF_)                                                                                       \
+  if (nt == NT_ && kt == KT_) {                                                                                      \
+    if (p.bias_part) hipLaunchKernelGGL((gemm_tn_skinny_kernel<NT_, KT_, PF_, 1>), g, b, 0, st, p);                  \
+    else hipLaunchKernelGGL((gemm_tn_skinny_kernel<NT_, KT_, PF_, 0>), g, b, 0, st, p);                             \
+  }
+    SKINNY(1, 1, 4) SKINNY(2, 1, 4) SKINNY(3, 1, 3) SKINNY(4, 1, 3) SKINNY(1, 2, 4) SKINNY(2, 2, 3)
+#undef SKINNY
+    CVH_CHECK_LAUNCH();
+    return gemm_dw_finish(p, rows, N, KH, KW, C1, C2, Cin_real, dw, accumulate, st);
+  }
+  if (skinny_shape) p.m_per_split = mps / 4;  // same partial-row count from the general kernel
+  dim3 grid(out_tiles, rows);
   if (fx && p.dy_xf.mode == 2) {
     return -2;  // not instantiated (see gemm_fx.hip): the linear case goes through cvh_bn_dw_combine
   } else if (fx) {
@@ -213,6 +255,7 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 1>), grid, dim3(256), 0, st, p);
     else return -1;
   } else if (dtype == CVH_DT_BF16 && p.part != nullptr && gemm_tn_big_eligible(p)) {  // transformer-sized linears (ViT-B / CLIP)
+    if (p.bias_part != nullptr) return -2;  // cvh_gemm_dw_folds_bias() says so
     const int rc = launch_gemm_tn_big(p, splits, st);
     if (rc) return rc;
   } else if (dtype == CVH_DT_BF16) {
@@ -221,6 +264,11 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
   } else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 0>), grid, dim3(256), 0, st, p);
   else return -1;
   CVH_CHECK_LAUNCH();
+  return gemm_dw_finish(p, rows, N, KH, KW, C1, C2, Cin_real, dw, accumulate, st);
+}
+
+static int gemm_dw_finish(const GemmTNParams& p, int splits, int N, int KH, int KW, int C1, int C2, int Cin_real, float* dw, int accumulate,
+                          hipStream_t st) {
   if (dw == nullptr) return p.part ? 0 : -2;  // partial tiles only: the caller sums the splits later (cvh_reduce_multi)
   if (p.part && KH * KW == 1 && Cin_real == p.Ktot && ((size_t)N * p.Ktot) % 4 == 0 && splits <= 64 && (size_t)N * p.Ktot >= 65536) {
     const size_t total4 = (size_t)N * p.Ktot / 4;
@@ -238,16 +286,24 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
   return 0;
 }
 
-extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw,
-                           int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
-                           int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream) {
+extern "C" int cvh_gemm_dw_bias(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw, float* bias_part,
+                                int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                                int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream) {
   if ((C1 % 8) != 0 || (C2 % 8) != 0 || (N % 8) != 0) return -2;
   GemmTNParams p;
   p.dy = dy; p.src1 = src1; p.src2 = src2; p.C1 = C1; p.C2 = C2; p.dw = dw;
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
   p.M = B * Ho * Wo; p.N = N; p.Ktot = KH * KW * (C1 + C2); p.Cin_real = Cin_real;
   p.dy_xf = make_xf(nullptr); p.x_xf = make_xf(nullptr);
+  p.bias_part = bias_part;
   return gemm_dw_run(dtype, p, N, KH, KW, C1, C2, Cin_real, dw, scratch, scratch_elems, accumulate, (hipStream_t)stream, false);
+}
+
+extern "C" int cvh_gemm_dw(int dtype, const void* dy, const void* src1, const void* src2, int C1, int C2, float* dw,
+                           int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
+                           int Cin_real, float* scratch, long long scratch_elems, int accumulate, void* stream) {
+  return cvh_gemm_dw_bias(dtype, dy, src1, src2, C1, C2, dw, nullptr, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, scratch,
+                          scratch_elems, accumulate, stream);
 }
 
 // Pointwise dW with both operands transformed on load: dy = ca*g + cb*y + cc (BatchNorm input gradient formed on the fly), x =
@@ -261,6 +317,7 @@ extern "C" int cvh_pw_gemm_dw_bn(int dtype, const void* dy, const cvh_operand_xf
   p.B = (int)M; p.H = 1; p.W = 1; p.Ho = 1; p.Wo = 1; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
   p.M = (int)M; p.N = N; p.Ktot = K; p.Cin_real = Cin_real;
   p.dy_xf = make_xf(dy_xf); p.x_xf = make_xf(x_xf);
+  p.bias_part = nullptr;
   if (p.dy_xf.mode == 2 && p.dy_xf.src2 == nullptr) return -2;
   return gemm_dw_run(dtype, p, N, 1, 1, K, 0, Cin_real, dw, scratch, scratch_elems, accumulate, (hipStream_t)stream, true);
 }

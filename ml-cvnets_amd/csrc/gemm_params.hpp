@@ -49,6 +49,7 @@ struct GemmTNParams {
   int m_per_split;
   int k_tiles;
   float* part;  // [splits][N][Ktot] partial products (no atomics); nullptr -> fp32 atomics straight into dw
+  float* bias_part;  // optional [rows][N] column sums of dY over each partial row's m-range (the bias gradient of the same layer)
   OperandXf dy_xf, x_xf;  // gemm_tn_kernel<..., FX = 1>: operand transforms on load (pointwise only)
 };
 

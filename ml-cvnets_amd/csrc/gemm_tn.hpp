@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 
   const int m_begin = by * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
+  const bool do_bias = p.bias_part != nullptr && tile_k == 0;
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
 
   // PF register stages in flight per thread (each = 2 rows of dY + 2 rows of A): the ring is indexed statically by unrolling
   constexpr int PF = 4;
@@ -155,6 +159,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
             rx1[u] = v8_mask(rx1[u], vb && k_ok);
           }
         }
+        if (do_bias) {  // column sums of dY (bias gradient) ride along in the workgroups of the first k tile
+          float f0[8], f1[8];
+          v8_unpack(rd0[u], f0);
+          v8_unpack(rd1[u], f1);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += f0[j] + f1[j];
+        }
         store_transposed_pair(Dt + (nc * 8) * PITCH + 2 * mp, PITCH, rd0[u], rd1[u]);
         store_transposed_pair(Xt + (nc * 8) * PITCH + 2 * mp, PITCH, rx0[u], rx1[u]);
         __syncthreads();
@@ -174,6 +185,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
     }
   }
 
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = bsum[j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      if (mp == 0 && n_ok) p.bias_part[(size_t)by * p.N + n_col + j] = v;
+    }
+  }
   const int khw = p.KH * p.KW;
 #pragma unroll
   for (int fn = 0; fn < 2; ++fn)
@@ -199,4 +221,138 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         if (n < p.N) atomicAdd(p.dw + ((size_t)n * p.Cin_real + c2) * khw + t2, acc[fn][fk][r]);
       }
     }
+}
+
+// =============================================================================================
+// Skinny pointwise dW:  N <= 128, K <= 64 (the 1x1 convolutions of the early, high-resolution stages: M = B*H*W is millions of rows,
+// the output is one small tile).  gemm_tn_kernel spends such launches waiting: 3/4 of its lanes have no column to load and every
+// 32-row stage costs two workgroup barriers.  Here every wave streams its OWN 32-row stages (wave w of split s takes stages w, w+4,
+// ...) through a wave-private LDS region — no workgroup barrier anywhere — with all lanes loading: a "unit" is 32 columns x 32 rows
+// (lane = row pair x 8-column chunk, the conflict-free transposed-store mapping of gemm_tn_kernel), NT units of dY and KT of X per
+// stage, PF stages in flight per wave.  Every wave writes its own partial tile (rows of the scratch = 4 x splits); with BIAS the
+// column sums of dY (the bias gradient of the same layer) ride along.
+// =============================================================================================
+template <int NT, int KT, int PF, int BIAS>
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(GemmTNParams p) {
+  using T = bf16_t;
+  constexpr int PITCH = 36;
+  constexpr int WAVE_ELEMS = (NT + KT) * 32 * PITCH;
+  __shared__ __attribute__((aligned(16))) T lds[4 * WAVE_ELEMS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int by = xcd_chunk_id((int)blockIdx.x, (int)gridDim.x);
+  T* Dt = lds + wave * WAVE_ELEMS;
+  T* Xt = Dt + NT * 32 * PITCH;
+  const int mp = lane & 15, cq = lane >> 4;
+  const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+  const T* __restrict__ xs = reinterpret_cast<const T*>(p.src1);
+  const int N = p.N, K = p.Ktot;
+
+  f32x16_t acc[NT][KT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[i][j] = acc_zero();
+  float bs[BIAS ? NT : 1][8];
+#pragma unroll
+  for (int i = 0; i < (BIAS ? NT : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[i][j] = 0.0f;
+
+  const int m_begin = by * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  constexpr int STEP = 4 * 32;  // the four waves interleave 32-row stages: one workgroup reads 128 consecutive rows at a time
+
+  V8<T> rd[PF][NT][2], rx[PF][KT][2];
+  auto load_stage = [&](V8<T> (&d)[NT][2], V8<T> (&x)[KT][2], int ms) __attribute__((always_inline)) {
+    const int ma = ms + 2 * mp, mb = ma + 1;
+    const bool va = ma < m_end, vb = mb < m_end;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = t * 32 + cq * 8;
+      d[t][0] = v8_load_clamped<T>(dy, (size_t)ma * N + col, va && col < N);
+      d[t][1] = v8_load_clamped<T>(dy, (size_t)mb * N + col, vb && col < N);
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int col = t * 32 + cq * 8;
+      x[t][0] = v8_load_clamped<T>(xs, (size_t)ma * K + col, va && col < K);
+      x[t][1] = v8_load_clamped<T>(xs, (size_t)mb * K + col, vb && col < K);
+    }
+  };
+
+  const int ms_w = m_begin + wave * 32;
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (ms_w + u * STEP < m_end) load_stage(rd[u], rx[u], ms_w + u * STEP);
+  for (int ms0 = ms_w; ms0 < m_end; ms0 += PF * STEP) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int ms = ms0 + u * STEP;
+      if (ms < m_end) {  // uniform across the wave
+        const bool va = ms + 2 * mp < m_end, vb = ms + 2 * mp + 1 < m_end;
+        wave_lds_sync();  // the fragment reads of the previous stage are behind us
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bool ok = t * 32 + cq * 8 < N;
+          const V8<T> d0 = v8_mask(rd[u][t][0], va && ok), d1 = v8_mask(rd[u][t][1], vb && ok);
+          if (BIAS) {
+            float f0[8], f1[8];
+            v8_unpack(d0, f0);
+            v8_unpack(d1, f1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs[t][j] += f0[j] + f1[j];
+          }
+          store_transposed_pair(Dt + (t * 32 + cq * 8) * PITCH + 2 * mp, PITCH, d0, d1);
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const bool ok = t * 32 + cq * 8 < K;
+          store_transposed_pair(Xt + (t * 32 + cq * 8) * PITCH + 2 * mp, PITCH, v8_mask(rx[u][t][0], va && ok), v8_mask(rx[u][t][1], vb && ok));
+        }
+        wave_lds_sync();
+        if (ms + PF * STEP < m_end) load_stage(rd[u], rx[u], ms + PF * STEP);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 16) {
+          Frag<T> a[NT], b[KT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) a[t] = lds_frag_a8(Dt, PITCH, t * 32, kk, lane);
+#pragma unroll
+          for (int t = 0; t < KT; ++t) b[t] = lds_frag_a8(Xt, PITCH, t * 32, kk, lane);
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) mma32(acc[i][j], a[i], b[j]);
+        }
+      }
+    }
+  }
+
+  const int row = by * 4 + wave;
+  float* dst = p.part + (size_t)row * N * K;
+#pragma unroll
+  for (int fn = 0; fn < NT; ++fn)
+#pragma unroll
+    for (int fk = 0; fk < KT; ++fk) {
+      const int k = fk * 32 + (lane & 31);
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = fn * 32 + acc_row(r, lane);
+        if (n < N) dst[(size_t)n * K + k] = acc[fn][fk][r];
+      }
+    }
+  if (BIAS) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = bs[t][j];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        const int n = t * 32 + cq * 8 + j;
+        if (mp == 0 && n < N) p.bias_part[(size_t)row * N + n] = v;
+      }
+  }
 }

@@ -32,6 +32,8 @@ SIGNATURES = {
     "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
     "cvh_conv_gemm_grid_rows": [I, I],
     "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
+    "cvh_gemm_dw_bias": [I, P, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
+    "cvh_gemm_dw_folds_bias": [I, I, I, I],
     "cvh_gemm_dw_scratch_elems": [I, I, I],
     "cvh_dwconv_fwd": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "cvh_dwconv_rows": [I, I, I, I, I, I, I, I],

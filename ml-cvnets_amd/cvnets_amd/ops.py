@@ -470,26 +470,42 @@ def _flush_deferred_reductions() -> None:
             _lib.call("cvh_reduce_multi", arr, len(items), _stream())
 
 
-def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real):
+_FOLD_BIAS = os.environ.get("CVH_FOLD_BIAS", "1") != "0"
+
+
+def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, bias_sink=None):
     """dW = dY^T x im2col(x): split over M into a scratch buffer + one reduce kernel (no atomics, no zero-fill).  Returns the
-    gradient tensor, or None when it was added in place into weight.grad."""
+    gradient tensor, or None when it was added in place into weight.grad.
+
+    With `bias_sink` (the .grad buffer of the same layer's bias) the return value is (dW, folded): folded == True means the bias
+    gradient was produced by the dW kernel itself (cvh_gemm_dw_bias: the column sums of dY ride along, dY is read once) and is summed into
+    bias_sink by the deferred reduction; False leaves it to the caller (cvh_colsum)."""
     sink = _grad_sink(weight)
-    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", B * Ho * Wo, N, KH * KW * (C1 + C2))
+    Ktot = KH * KW * (C1 + C2)
+    M = B * Ho * Wo
+    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, N, Ktot)
     side = _param_grad_stream(dy.device) if sink is not None else None
     if side is not None:
-        Ktot = KH * KW * (C1 + C2)
+        folded = False
         with torch.cuda.stream(side):
             scr = _f32(max(n_scr, 1), dy.device)
             for t in (dy, x, x2):
                 if t is not None:
                     t.record_stream(side)
             # split partials now, their sum at the end of backward (cvh_reduce_multi) — or right here when deferral is off
-            deferred = n_scr > 0 and defer_reduce(scr, sink, n_scr // (N * Ktot), N * Ktot, N * Ktot,
+            rows = n_scr // (N * Ktot)
+            deferred = n_scr > 0 and defer_reduce(scr, sink, rows, N * Ktot, N * Ktot,
                                                   kind=0 if (KH * KW == 1 and Cin_real == Ktot) else 1, N=N, Ktot=Ktot, Cin=C1 + C2,
                                                   Cin_real=Cin_real, khw=KH * KW)
-            _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, None if deferred else _p(sink), B, H, W, Ho, Wo, KH, KW, stride,
-                      pad, dil, N, Cin_real, _p(scr), n_scr, 1, _stream())
-        return None
+            bpart = None
+            if (bias_sink is not None and deferred and _FOLD_BIAS and _lib.query("cvh_gemm_dw_folds_bias", _dt(dy), M, N, Ktot)):
+                bpart = _f32(rows * N, dy.device)
+                folded = defer_reduce(bpart, bias_sink, rows, N, N)
+            _lib.call("cvh_gemm_dw_bias", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, None if deferred else _p(sink), _p(bpart) if folded else None,
+                      B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, _p(scr), n_scr, 1, _stream())
+        return (None, folded) if bias_sink is not None else None
+    if bias_sink is not None:
+        return _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real), False
     dw = sink if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
     scr = _f32(max(n_scr, 1), dy.device)
     _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real,
@@ -592,9 +608,15 @@ class ConvBNAct(torch.autograd.Function):
             dy = _act_backward(y, dout, act, M, Cout)
         else:
             dy = dout
-        if ctx.has_bias:
-            dbias = _colsum(dy, M, Cout, _grad_sink(bias_p))
-        dw_ret = _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real)
+        bsink = _grad_sink(bias_p) if ctx.has_bias else None
+        if bsink is not None:  # the bias gradient rides along in the dW kernel where it can
+            dw_ret, folded = _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real, bias_sink=bsink)
+            if not folded:
+                _colsum(dy, M, Cout, bsink)
+        else:
+            if ctx.has_bias:
+                dbias = _colsum(dy, M, Cout, None)
+            dw_ret = _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, Cin_real)
         dx = dx2 = None
         need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
         if need1 or need2:
@@ -789,8 +811,16 @@ class LinearAct(torch.autograd.Function):
                 dy = _act_backward(pre, dy, act, rows, N)
             if expose_pre and dpre is not None:
                 dy = add(dy, dpre.contiguous())
-        dbias = _colsum(dy, rows, N, _grad_sink(ctx.bias)) if ctx.has_bias else None
-        dw_ret = _weight_grad(dy, x, None, K, 0, weight, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K)
+        dbias = None
+        bsink = _grad_sink(ctx.bias) if ctx.has_bias else None
+        if bsink is not None:  # the bias gradient rides along in the dW kernel where it can
+            dw_ret, folded = _weight_grad(dy, x, None, K, 0, weight, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K, bias_sink=bsink)
+            if not folded:
+                _colsum(dy, rows, N, bsink)
+        else:
+            if ctx.has_bias:
+                dbias = _colsum(dy, rows, N, None)
+            dw_ret = _weight_grad(dy, x, None, K, 0, weight, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K)
         dx = d_in_pre = None
         if ctx.needs_input_grad[0] or (in_pre is not None and ctx.needs_input_grad[4]):
             wpt = pack_weight(weight, dtype, 1)  # [K][N]

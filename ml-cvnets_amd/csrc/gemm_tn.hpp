@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const T* s = reinterpret_cast<const T*>(p.src1);
   int cs = p.C1, cc = c;
-  if (!FX && c >= p.C1) { s = reinterpret_cast<const T*>(p.src2); cs = p.C2; cc = c - p.C1; }  // FX: single source; predicated loads need a valid base
+  if (!FX && k_ok && c >= p.C1) { s = reinterpret_cast<const T*>(p.src2); cs = p.C2; cc = c - p.C1; }  // k_ok: lanes without a column keep the (always valid) first source as the base of their clamped loads
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
   Coef8 kd, kx;
   if (FX && dy_mode) coef8_load(kd, p.dy_xf, n_col, n_ok);
   if (FX && x_mode) coef8_load(kx, p.x_xf, k_col, k_ok);
-  auto load_stage = [&](V8<T>& d0, V8<T>& d1, V8<T>& x0, V8<T>& x1, V8<T>& y0, V8<T>& y1, int ms) __attribute__((always_inline)) {
+  unsigned okm = 0;  // non-FX: validity bits of the ring slots (d0, d1, x0, x1 per slot)
+  auto load_stage = [&](V8<T>& d0, V8<T>& d1, V8<T>& x0, V8<T>& x1, V8<T>& y0, V8<T>& y1, int ms, int slot) __attribute__((always_inline)) {
     const int ma = ms + 2 * mp, mb = ma + 1;
     if (FX) {  // pointwise by construction; clamped loads, masked where they are consumed (store to LDS)
       const bool va = ma < m_end, vb = mb < m_end;
@@ -103,44 +104,53 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
       }
       return;
     }
-    d0 = d1 = x0 = x1 = v8_zero<T>();
-    if (n_ok) {
-      if (ma < m_end) d0 = v8_load<T>(dy + (size_t)ma * p.N + n_col);
-      if (mb < m_end) d1 = v8_load<T>(dy + (size_t)mb * p.N + n_col);
-    }
-    if (k_ok) {
+    // Branch-free: clamped addresses, validity kept as 4 bits per ring slot and applied where the values are consumed.  (Per-lane
+    // `if (ok) v = load` puts the loads behind exec-mask branches; the compiler can then no longer COUNT the loads in flight, every wait
+    // becomes s_waitcnt vmcnt(0) and the 4-deep ring degenerates to one memory latency per stage — tools/waitcnt_survey.py.)
+    {
+      const bool va = ma < m_end && n_ok, vb = mb < m_end && n_ok;
+      d0 = v8_load_clamped<T>(dy, (size_t)ma * p.N + n_col, va);
+      d1 = v8_load_clamped<T>(dy, (size_t)mb * p.N + n_col, vb);
+      bool xa, xb;
       if (pointwise) {
-        if (ma < m_end) x0 = v8_load<T>(s + (size_t)ma * cs + cc);
-        if (mb < m_end) x1 = v8_load<T>(s + (size_t)mb * cs + cc);
+        xa = ma < m_end && k_ok;
+        xb = mb < m_end && k_ok;
+        x0 = v8_load_clamped<T>(s, (size_t)ma * cs + cc, xa);
+        x1 = v8_load_clamped<T>(s, (size_t)mb * cs + cc, xb);
       } else {
         const int hw = p.Ho * p.Wo;
+        size_t off[2];
+        bool okx[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int m = e ? mb : ma;
-          if (m < m_end) {
-            int b = m / hw;
-            int rem = m - b * hw;
-            int ho = rem / p.Wo;
-            int wo = rem - ho * p.Wo;
-            int hi = ho * p.stride - p.pad + kh * p.dil, wi = wo * p.stride - p.pad + kw * p.dil;
-            if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
-              V8<T> v = v8_load<T>(s + ((size_t)(b * p.H + hi) * p.W + wi) * cs + cc);
-              if (e) x1 = v; else x0 = v;
-            }
-          }
+          const int b = m / hw;
+          const int rem = m - b * hw;
+          const int ho = rem / p.Wo;
+          const int wo = rem - ho * p.Wo;
+          const int hi = ho * p.stride - p.pad + kh * p.dil, wi = wo * p.stride - p.pad + kw * p.dil;
+          okx[e] = m < m_end && k_ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+          off[e] = ((size_t)(b * p.H + hi) * p.W + wi) * cs + cc;
         }
+        xa = okx[0];
+        xb = okx[1];
+        x0 = v8_load_clamped<T>(s, off[0], xa);
+        x1 = v8_load_clamped<T>(s, off[1], xb);
       }
+      const unsigned bits = (va ? 1u : 0u) | (vb ? 2u : 0u) | (xa ? 4u : 0u) | (xb ? 8u : 0u);
+      okm = (okm & ~(15u << (4 * slot))) | (bits << (4 * slot));
     }
   };
 
+  // No control flow inside the ring: every group of PF stages runs completely — stages past m_end load zeros (all lanes predicated
+  // off) and add nothing — so that the compiler can count the loads in flight at every wait.
 #pragma unroll
-  for (int u = 0; u < PF; ++u)
-    if (m_begin + u * BMR < m_end) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ry0[FX == 2 ? u : 0], ry1[FX == 2 ? u : 0], m_begin + u * BMR);
+  for (int u = 0; u < PF; ++u) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ry0[FX == 2 ? u : 0], ry1[FX == 2 ? u : 0], m_begin + u * BMR, u);
   for (int ms0 = m_begin; ms0 < m_end; ms0 += PF * BMR) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int ms = ms0 + u * BMR;
-      if (ms < m_end) {  // uniform across the workgroup
+      {
         __syncthreads();
         if (FX) {  // rows beyond m_end (and columns beyond N / K) must contribute zero AFTER the transform: the reduction runs over m
           const bool va = ms + 2 * mp < m_end, vb = ms + 2 * mp + 1 < m_end;
@@ -159,6 +169,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
             rx1[u] = v8_mask(rx1[u], vb && k_ok);
           }
         }
+        if (!FX) {
+          const unsigned bits = okm >> (4 * u);
+          rd0[u] = v8_mask(rd0[u], (bits & 1u) != 0);
+          rd1[u] = v8_mask(rd1[u], (bits & 2u) != 0);
+          rx0[u] = v8_mask(rx0[u], (bits & 4u) != 0);
+          rx1[u] = v8_mask(rx1[u], (bits & 8u) != 0);
+        }
         if (do_bias) {  // column sums of dY (bias gradient) ride along in the workgroups of the first k tile
           float f0[8], f1[8];
           v8_unpack(rd0[u], f0);
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
         store_transposed_pair(Dt + (nc * 8) * PITCH + 2 * mp, PITCH, rd0[u], rd1[u]);
         store_transposed_pair(Xt + (nc * 8) * PITCH + 2 * mp, PITCH, rx0[u], rx1[u]);
         __syncthreads();
-        if (ms + PF * BMR < m_end) load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ry0[FX == 2 ? u : 0], ry1[FX == 2 ? u : 0], ms + PF * BMR);
+        load_stage(rd0[u], rd1[u], rx0[u], rx1[u], ry0[FX == 2 ? u : 0], ry1[FX == 2 ? u : 0], ms + PF * BMR, u);
 #pragma unroll
         for (int kk = 0; kk < BMR; kk += 16) {
           Frag<T> a0 = PV == 1 ? lds_frag_a8(Dt, PITCH, wave_n * 64, kk, lane) : lds_frag(Dt, PITCH, wave_n * 64, kk, lane);
@@ -281,14 +298,14 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(GemmTNParams p) {
   };
 
   const int ms_w = m_begin + wave * 32;
+  // no control flow inside the ring (see gemm_tn_kernel): stages past m_end are fully predicated off and add nothing
 #pragma unroll
-  for (int u = 0; u < PF; ++u)
-    if (ms_w + u * STEP < m_end) load_stage(rd[u], rx[u], ms_w + u * STEP);
+  for (int u = 0; u < PF; ++u) load_stage(rd[u], rx[u], ms_w + u * STEP);
   for (int ms0 = ms_w; ms0 < m_end; ms0 += PF * STEP) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int ms = ms0 + u * STEP;
-      if (ms < m_end) {  // uniform across the wave
+      {
         const bool va = ms + 2 * mp < m_end, vb = ms + 2 * mp + 1 < m_end;
         wave_lds_sync();  // the fragment reads of the previous stage are behind us
 #pragma unroll
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(GemmTNParams p) {
           store_transposed_pair(Xt + (t * 32 + cq * 8) * PITCH + 2 * mp, PITCH, v8_mask(rx[u][t][0], va && ok), v8_mask(rx[u][t][1], vb && ok));
         }
         wave_lds_sync();
-        if (ms + PF * STEP < m_end) load_stage(rd[u], rx[u], ms + PF * STEP);
+        load_stage(rd[u], rx[u], ms + PF * STEP);
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 16) {
           Frag<T> a[NT], b[KT];

@@ -318,6 +318,15 @@ int cvh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, const unsign
 int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
                  const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
                  int causal, void* stream);
+/* The same with dropout on the attention probabilities (MultiHeadAttention.attn_dropout, cvnets/layers/multi_head_attention.py:217-218):
+ * O = dropout(softmax(S)) V.  The keep mask is a counter-based function of (*seed, stream_id, sequence, head, query, key) — the generator
+ * of cvh_dropout — regenerated by the backward kernels, never stored; drop_p == 0 is cvh_attn_fwd / cvh_attn_bwd. */
+int cvh_attn_fwd_drop(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, int nseq, int S, int h, int c,
+                      int ph, int pw, int n_w, int H, int W, float scaling, int causal, float drop_p,
+                      const unsigned long long* seed, unsigned int stream_id, void* stream);
+int cvh_attn_bwd_drop(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                      const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
+                      int causal, float drop_p, const unsigned long long* seed, unsigned int stream_id, void* stream);
 
 /* experiment knob for tools/kernel_bench.py (A/B of kernel variants in one process); never needed for correct results */
 int cvh_set_tuning(int key, int value);

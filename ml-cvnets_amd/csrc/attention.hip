@@ -28,7 +28,18 @@ struct AttnParams {
   SeqMap map;
   float scaling;
   int causal;
+  // dropout on the attention probabilities (MultiHeadAttention.attn_dropout, cvnets/layers/multi_head_attention.py:217): the keep mask is
+  // a function of (seed, stream, sequence, head, query, key) and is REGENERATED in the backward kernels, never stored
+  float drop_p;
+  const unsigned long long* seed;
+  unsigned int stream_id;
 };
+
+// keep-scale (0 or 1/(1-p)) of one attention probability
+__device__ __forceinline__ float attn_keep(const AttnParams& p, unsigned long long seed, float inv_keep, int s, int head, int q, int key) {
+  const unsigned long long idx = (((unsigned long long)s * p.h + head) * p.S + q) * (unsigned long long)p.S + key;
+  return dropout_scale(seed, p.stream_id, idx, p.drop_p, inv_keep);
+}
 
 
 template <typename T, int VEC> __device__ __forceinline__ void ld_vec(const T* p, float* f) {
@@ -238,6 +249,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   }
 
   const int my_q = q0 + (lane & 31);
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   float m_run = -1e30f, l_run = 0.f;
   f32x16_t oacc[NFC];
 #pragma unroll
@@ -281,15 +295,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = fast_exp(m_run - m_new);
     float rs = 0.f;
 #pragma unroll
     for (int f = 0; f < KB / 32; ++f) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __expf(sv[f][r] - m_new);
+        float pv = fast_exp(sv[f][r] - m_new);
+        rs += pv;  // the softmax normaliser runs over the undropped probabilities
+        if (drop) pv *= attn_keep(p, seed, inv_keep, s, head, my_q, kv0 + f * 32 + acc_row(r, lane));
         sv[f][r] = pv;
-        rs += pv;
       }
       store_acc_transposed<T>(Ps, PP, f * 32, sv[f], lane);
     }
@@ -455,6 +470,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   const bool q_ok = my_q < p.S;
   const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
   const float lse = p.lse[sidx], dsum = p.dsum[sidx];
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
   f32x16_t dqacc[NFC];
 #pragma unroll
@@ -494,7 +512,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
           const int key = kv0 + f * 32 + acc_row(r, lane);
           vis = q_ok && key_visible(p, s, key, my_q);
         }
-        ds[r] = vis ? __expf(sacc[f][r] - lse) * (dpacc[f][r] - dsum) : 0.f;
+        float dpv = dpacc[f][r];
+        if (drop) dpv *= attn_keep(p, seed, inv_keep, s, head, my_q, kv0 + f * 32 + acc_row(r, lane));  // dP = keep * (dO V^T)
+        ds[r] = vis ? fast_exp(sacc[f][r] - lse) * (dpv - dsum) : 0.f;
       }
       store_acc_transposed<T>(dSs, PP, f * 32, ds, lane);
     }
@@ -600,6 +620,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   f32x16_t dkacc[NFC], dvacc[NFC];
 #pragma unroll
   for (int f = 0; f < NFC; ++f) { dkacc[f] = acc_zero(); dvacc[f] = acc_zero(); }
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
   while (qb_next < p.S) {
     const int qb0 = qb_next;
@@ -633,9 +656,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
         const int key = k0 + acc_row(r, lane);
         vis = q_ok && key_visible(p, s, key, my_q);
       }
-      const float pv = vis ? __expf(sacc[r] - lse) : 0.f;
-      pt[r] = pv;
-      dsv[r] = pv * (dpacc[r] - dsum);
+      const float pv = vis ? fast_exp(sacc[r] - lse) : 0.f;
+      const float keep = drop ? attn_keep(p, seed, inv_keep, s, head, my_q, k0 + acc_row(r, lane)) : 1.0f;
+      pt[r] = pv * keep;                          // dV = (keep * P)^T dO
+      dsv[r] = pv * (dpacc[r] * keep - dsum);     // dS = P * (keep * dP - D)
     }
     store_acc_natural<T>(PTs, PT, 0, 0, pt, lane);    // PTs[key][q]
     store_acc_natural<T>(dSTs, PT, 0, 0, dsv, lane);  // dSTs[key][q]
@@ -682,6 +706,7 @@ static AttnParams make_params(const void* qkv, void* out, const void* dout, void
   p.nseq = nseq; p.S = S; p.h = h; p.c = c; p.d = h * c;
   p.map.ph = ph; p.map.pw = pw; p.map.n_w = n_w; p.map.H = H; p.map.W = W;
   p.scaling = scaling; p.causal = causal;
+  p.drop_p = 0.f; p.seed = nullptr; p.stream_id = 0;
   return p;
 }
 
@@ -736,18 +761,33 @@ static int dispatch_attn(int dtype, int which, const AttnParams& p, hipStream_t 
   return -1;
 }
 
+extern "C" int cvh_attn_fwd_drop(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, int nseq, int S, int h, int c,
+                                 int ph, int pw, int n_w, int H, int W, float scaling, int causal, float drop_p,
+                                 const unsigned long long* seed, unsigned int stream_id, void* stream) {
+  if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && seed == nullptr)) return -2;
+  AttnParams p = make_params(qkv, out, nullptr, nullptr, lse, nullptr, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
+  p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
+  return dispatch_attn(dtype, K_FWD, p, (hipStream_t)stream);
+}
 extern "C" int cvh_attn_fwd(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, int nseq, int S, int h, int c,
                             int ph, int pw, int n_w, int H, int W, float scaling, int causal, void* stream) {
-  if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
-  AttnParams p = make_params(qkv, out, nullptr, nullptr, lse, nullptr, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
-  return dispatch_attn(dtype, K_FWD, p, (hipStream_t)stream);
+  return cvh_attn_fwd_drop(dtype, qkv, out, lse, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal, 0.f, nullptr, 0, stream);
 }
 
 extern "C" int cvh_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
                             const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
                             int causal, void* stream) {
+  return cvh_attn_bwd_drop(dtype, qkv, out, dout, dqkv, lse, dsum, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal, 0.f, nullptr, 0, stream);
+}
+
+extern "C" int cvh_attn_bwd_drop(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                                 const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
+                                 int causal, float drop_p, const unsigned long long* seed, unsigned int stream_id, void* stream) {
   if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && seed == nullptr)) return -2;
   AttnParams p = make_params(qkv, nullptr, dout, dqkv, const_cast<float*>(lse), dsum, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
+  p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
   hipStream_t st = (hipStream_t)stream;
   {
     size_t total = (size_t)nseq * h * S;

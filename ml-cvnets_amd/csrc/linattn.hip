@@ -216,7 +216,7 @@ __device__ __forceinline__ void la_scores(const LaGeom& g, const T* __restrict__
   mx = block_max(mx, scr);
   float sum = 0.f;
   for (int n = threadIdx.x; n < g.N; n += 256) {
-    const float e = __expf(s[n] - mx);
+    const float e = fast_exp(s[n] - mx);
     s[n] = e;
     sum += e;
   }

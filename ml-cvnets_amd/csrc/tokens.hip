@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) scaled_ce_fwd_kernel(const T* __restrict_
   __syncthreads();
   mx = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
   float sum = 0.f;
-  for (int j = threadIdx.x; j < M; j += 256) sum += __expf(s * to_f<T>(row[j]) - mx);
+  for (int j = threadIdx.x; j < M; j += 256) sum += fast_exp(s * to_f<T>(row[j]) - mx);
   sum = wave_sum(sum);
   if ((threadIdx.x & 63) == 0) scr[4 + (threadIdx.x >> 6)] = sum;
   __syncthreads();
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) scaled_ce_bwd_kernel(const T* __restrict_
   float acc = 0.f;
   for (int j = threadIdx.x; j < M; j += 256) {
     const float x = to_f<T>(row[j]);
-    const float d = __expf(s * x - l) - (j == label ? 1.f : 0.f);
+    const float d = fast_exp(s * x - l) - (j == label ? 1.f : 0.f);
     acc += x * d;
     dlogits[(size_t)i * M + j] = from_f<T>(g * s * d);
   }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
   mx = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
   sm = (scr[4] + scr[5]) + (scr[6] + scr[7]);
   float ex = 0.f;
-  for (int j = threadIdx.x; j < M; j += 256) ex += __expf(to_f<T>(row[j]) - mx);
+  for (int j = threadIdx.x; j < M; j += 256) ex += fast_exp(to_f<T>(row[j]) - mx);
   ex = wave_sum(ex);
   if ((threadIdx.x & 63) == 0) scr[8 + (threadIdx.x >> 6)] = ex;
   __syncthreads();
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
   const long long y = labels[i];
   const float l = lse[i], g = (y == ignore_index) ? 0.f : *gout, u = eps / (float)M;
   for (int j = threadIdx.x; j < M; j += 256) {
-    const float p = __expf(to_f<T>(logits[(size_t)i * M + j]) - l);
+    const float p = fast_exp(to_f<T>(logits[(size_t)i * M + j]) - l);
     dlogits[(size_t)i * M + j] = from_f<T>(g * (p - (j == y ? 1.f - eps : 0.f) - u));
   }
 }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void ce_soft_fwd_kernel(const T* __restrict__ 
   tz = (scr[12] + scr[13]) + (scr[14] + scr[15]);
   __syncthreads();
   float ex = 0.f;
-  for (int j = threadIdx.x; j < M; j += 256) ex += __expf(to_f<T>(row[j]) - mx);
+  for (int j = threadIdx.x; j < M; j += 256) ex += fast_exp(to_f<T>(row[j]) - mx);
   ex = wave_sum(ex);
   if ((threadIdx.x & 63) == 0) scr[wv] = ex;
   __syncthreads();
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void ce_soft_bwd_kernel(const T* __restrict__ 
   const int i = blockIdx.x;
   const float l = lse[i], w = tsum[i], g = *gout, u = eps / (float)M;
   for (int j = threadIdx.x; j < M; j += 256) {
-    const float p = __expf(to_f<T>(logits[(size_t)i * M + j]) - l);
+    const float p = fast_exp(to_f<T>(logits[(size_t)i * M + j]) - l);
     dlogits[(size_t)i * M + j] = from_f<T>(g * (p * w - (1.f - eps) * target[(size_t)i * M + j] - u));
   }
 }

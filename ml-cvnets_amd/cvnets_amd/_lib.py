@@ -98,6 +98,8 @@ SIGNATURES = {
     "cvh_dwconv_bn_bwd": [I, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, I, P],
     "cvh_attn_fwd": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
+    "cvh_attn_fwd_drop": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
+    "cvh_attn_bwd_drop": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
 }
 
 class OperandXf(ctypes.Structure):

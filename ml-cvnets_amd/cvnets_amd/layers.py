@@ -542,10 +542,10 @@ class MultiHeadAttention(nn.Module):
     def forward_tokens(self, x2d: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None, out_drop_p: float = 0.0,
                        residual: Optional[Tensor] = None) -> Tensor:
         """qkv projection -> fused attention -> output projection (+dropout +residual in its epilogue)."""
-        if self.attn_dropout.p > 0.0 and self.training:
-            raise NotImplementedError("attention-probability dropout is not implemented in the fused kernel (reference YAMLs use 0.0)")
         qkv = ops.linear(x2d, self.qkv_proj.weight, self.qkv_proj.bias)
-        o = ops.attention(qkv, self.num_heads, seqmap, causal=causal, key_padding_mask=key_padding_mask)
+        # attn_dropout (multi_head_attention.py:217-218) acts on the softmax output inside the fused kernel; the mask is regenerated in backward
+        o = ops.attention(qkv, self.num_heads, seqmap, causal=causal, key_padding_mask=key_padding_mask,
+                          drop_p=float(self.attn_dropout.p) if self.training else 0.0)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, drop_p=out_drop_p, residual=residual)
 
     def forward(self, x_q: Tensor, x_kv: Optional[Tensor] = None, key_padding_mask: Optional[Tensor] = None,

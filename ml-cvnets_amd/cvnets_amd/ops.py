@@ -931,7 +931,7 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, kpm, cfg):
-        heads, seqmap, causal = cfg
+        heads, seqmap, causal, drop_p, stream_id = cfg
         nseq, S, ph, pw, n_w, H, W = seqmap
         _check_dev(qkv)
         rows, d3 = qkv.shape
@@ -941,15 +941,17 @@ class AttentionFn(torch.autograd.Function):
             raise NotImplementedError("head_dim > 64")
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
         lse = _f32(nseq * heads * S, qkv.device)
-        _lib.call("cvh_attn_fwd", _dt(qkv), _p(qkv), _p(out), _p(lse), _p(kpm), nseq, S, heads, c, ph, pw, n_w, H, W, float(c) ** -0.5,
-                  1 if causal else 0, _stream())
+        seed = dropout_seed(qkv.device) if drop_p > 0 else None  # the backward regenerates the keep mask from the same seed / stream id
+        _lib.call("cvh_attn_fwd_drop", _dt(qkv), _p(qkv), _p(out), _p(lse), _p(kpm), nseq, S, heads, c, ph, pw, n_w, H, W, float(c) ** -0.5,
+                  1 if causal else 0, float(drop_p), _p(seed), stream_id, _stream())
         ctx.cfg = cfg
+        ctx.seed = seed
         ctx.save_for_backward(qkv, out, lse, kpm)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        heads, seqmap, causal = ctx.cfg
+        heads, seqmap, causal, drop_p, stream_id = ctx.cfg
         nseq, S, ph, pw, n_w, H, W = seqmap
         qkv, out, lse, kpm = ctx.saved_tensors
         d = qkv.shape[1] // 3
@@ -957,16 +959,19 @@ class AttentionFn(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         dsum = _f32(nseq * heads * S, qkv.device)
-        _lib.call("cvh_attn_bwd", _dt(qkv), _p(qkv), _p(out), _p(dout), _p(dqkv), _p(lse), _p(dsum), _p(kpm), nseq, S, heads, c, ph, pw, n_w,
-                  H, W, float(c) ** -0.5, 1 if causal else 0, _stream())
+        _lib.call("cvh_attn_bwd_drop", _dt(qkv), _p(qkv), _p(out), _p(dout), _p(dqkv), _p(lse), _p(dsum), _p(kpm), nseq, S, heads, c, ph, pw, n_w,
+                  H, W, float(c) ** -0.5, 1 if causal else 0, float(drop_p), _p(ctx.seed), stream_id, _stream())
         return dqkv, None, None
 
 
-def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None):
+def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None,
+              drop_p: float = 0.0):
+    """drop_p > 0: dropout on the attention probabilities (the caller passes it in training mode only), mask regenerated in backward"""
     kpm = None
     if key_padding_mask is not None:
         kpm = (key_padding_mask != 0).to(torch.uint8).contiguous()  # plumbing; any non-zero entry (True, 1, -inf) masks the key, as .to(torch.bool) does in the reference
-    return AttentionFn.apply(qkv2d, kpm, (int(heads), tuple(int(v) for v in seqmap), bool(causal)))
+    sid = next_stream_id() if drop_p > 0 else 0
+    return AttentionFn.apply(qkv2d, kpm, (int(heads), tuple(int(v) for v in seqmap), bool(causal), float(drop_p), sid))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -125,7 +125,11 @@ extern "C" int cvh_conv_dx_patch(int dtype, const void* dy, const void* wgt, voi
   return -1;
 }
 
-static bool tn_big_shape(int M, int N, int Ktot) { return M >= 2048 && N >= 256 && (N % 128) == 0 && Ktot >= 256 && (Ktot % 128) == 0; }
+static bool tn_skinny_shape(int M, int N, int Ktot);
+// shapes of the direct-to-LDS dW kernel (gemm_big.hip: gemm_tn128_kernel; its eligibility also needs a plain pointwise bf16 problem)
+static bool tn_big_shape(int M, int N, int Ktot) {
+  return M >= 2048 && N >= 64 && (N % 8) == 0 && Ktot >= 64 && (Ktot % 8) == 0 && !tn_skinny_shape(M, N, Ktot);
+}
 
 // one small output tile under millions of rows (gemm_tn.hpp: gemm_tn_skinny_kernel).  A property of the SHAPE alone, so that the scratch
 // size query needs no more than (M, N, Ktot): such problems always produce 4 partial rows per split; launches the skinny kernel cannot
@@ -148,7 +152,7 @@ static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* s
     const int slots = 512, total_steps = (M + 63) / 64;
     double best = 1e30;
     sp = 1;
-    for (int s = 1; s <= 32 && s <= total_steps; ++s) {
+    for (int s = 1; s <= 512 && s * 4 <= total_steps + 3; ++s) {  // at least ~4 steps (256 rows) per split
       const int rounds = (*out_tiles * s + slots - 1) / slots;
       const int steps = (total_steps + s - 1) / s;
       const double t = (double)rounds * steps * 1.8 + (double)(s + 1) * (double)N * Ktot * 4.0 / 3.0e6;  // microseconds
@@ -259,7 +263,8 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     const int rc = launch_gemm_tn_big(p, splits, st);
     if (rc) return rc;
   } else if (dtype == CVH_DT_BF16) {
-    if (cvh_tune_get(CVH_TUNE_TN_PITCH)) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 1, 0>), grid, dim3(256), 0, st, p);
+    const bool pw = KH * KW == 1 && p.stride == 1 && p.pad == 0;
+    if (pw) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 1, 0>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0, 0>), grid, dim3(256), 0, st, p);
   } else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 0>), grid, dim3(256), 0, st, p);
   else return -1;

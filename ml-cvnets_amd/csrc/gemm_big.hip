@@ -226,12 +226,20 @@ __device__ __forceinline__ Frag<bf16_t> frag_tr(const unsigned char* img, int kk
 }
 }  // namespace
 
+// RAGGED: N and K need not be multiples of 128 (only of 8): 16-byte column chunks past the end of a row read the zero line instead, and the
+// output columns they feed are not stored.  That opens the direct-to-LDS path — no VALU work between HBM and the MFMA operands — to the
+// transformer / fusion linears of MobileViT (N, K in 96 ... 720), where gemm_tn_kernel's unpack / mask / pack work per loaded element
+// (~115 VALU instructions per 8 MFMAs) serialises with the MFMAs and caps it at ~290 TFLOP/s-equivalent.
+template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (dY image 16 KB | X image 16 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_n = wave >> 1, wave_k = wave & 1;
-  const int n0 = (blockIdx.x / p.k_tiles) * 128, k0 = (blockIdx.x % p.k_tiles) * 128;
-  const int m_begin = blockIdx.y * p.m_per_split;
+  // XCD-contiguous work order, output tile fastest: the workgroups reducing the SAME rows (one per output tile) share one L2
+  const int bid_ = xcd_chunk_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int bx = bid_ % (int)gridDim.x, by = bid_ / (int)gridDim.x;
+  const int n0 = (bx / p.k_tiles) * 128, k0 = (bx % p.k_tiles) * 128;
+  const int m_begin = by * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(p.dy);
   const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.src1);
@@ -248,8 +256,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
     unsigned char* x_dst = y_dst + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      glds16(ok ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
-      glds16(ok ? gx + (size_t)step * 64 * K + j * 32 : zero, x_dst + j * 1024);
+      const bool oky = ok && (!RAGGED || n0 + j * 32 + (lane & 3) * 8 < N);
+      const bool okx = ok && (!RAGGED || k0 + j * 32 + (lane & 3) * 8 < K);
+      glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
+      glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : zero, x_dst + j * 1024);
     }
   };
 
@@ -285,16 +295,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
     __syncthreads();
   }
 
-  float* dst0 = p.part + (size_t)blockIdx.y * N * K;
+  float* dst0 = p.part + (size_t)by * N * K;
 #pragma unroll
   for (int fn = 0; fn < 2; ++fn)
 #pragma unroll
     for (int fk = 0; fk < 2; ++fk) {
       const int k = k0 + wave_k * 64 + fk * 32 + (lane & 31);
+      if (RAGGED && k >= K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
-        dst0[(size_t)n * K + k] = acc[fn][fk][r];
+        if (!RAGGED || n < N) dst0[(size_t)n * K + k] = acc[fn][fk][r];
       }
     }
 }
@@ -302,13 +313,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
 bool gemm_tn_big_eligible(const GemmTNParams& p) {
   if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
   const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
-  return linear && p.M >= 2048 && p.N >= 256 && (p.N % 128) == 0 && p.Ktot >= 256 && (p.Ktot % 128) == 0 && p.Cin_real == p.Ktot &&
+  return linear && p.M >= 2048 && p.N >= 64 && (p.N % 8) == 0 && p.Ktot >= 64 && (p.Ktot % 8) == 0 && p.Cin_real == p.Ktot &&
          (p.m_per_split % 64) == 0;
 }
 
 int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st) {
-  const int out_tiles = (p.N / 128) * (p.Ktot / 128);
-  hipLaunchKernelGGL(gemm_tn128_kernel, dim3(out_tiles, splits), dim3(256), 2 * BUF_BYTES, st, p);
+  const int out_tiles = ((p.N + 127) / 128) * ((p.Ktot + 127) / 128);
+  if ((p.N % 128) == 0 && (p.Ktot % 128) == 0) hipLaunchKernelGGL(gemm_tn128_kernel<false>, dim3(out_tiles, splits), dim3(256), 2 * BUF_BYTES, st, p);
+  else hipLaunchKernelGGL(gemm_tn128_kernel<true>, dim3(out_tiles, splits), dim3(256), 2 * BUF_BYTES, st, p);
   CVH_CHECK_LAUNCH();
   return 0;
 }

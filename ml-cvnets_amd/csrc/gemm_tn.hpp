@@ -16,8 +16,8 @@ __device__ __forceinline__ void store_transposed_pair(bf16_t* dst, int pitch, co
   const uint32_t a[4] = {r0.d.x, r0.d.y, r0.d.z, r0.d.w};
   const uint32_t b[4] = {r1.d.x, r1.d.y, r1.d.z, r1.d.w};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    uint32_t w = (j & 1) ? ((a[j >> 1] >> 16) | (b[j >> 1] & 0xffff0000u)) : ((a[j >> 1] & 0xffffu) | (b[j >> 1] << 16));
+  for (int j = 0; j < 8; ++j) {  // {row 2i element j, row 2i+1 element j}: one v_perm_b32 per packed word
+    const uint32_t w = __builtin_amdgcn_perm(b[j >> 1], a[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
     *reinterpret_cast<uint32_t*>(dst + j * pitch) = w;
   }
 }
@@ -29,8 +29,9 @@ __device__ __forceinline__ void store_transposed_pair(float* dst, int pitch, con
   for (int j = 0; j < 8; ++j) *reinterpret_cast<float2*>(dst + j * pitch) = make_float2(a[j], b[j]);
 }
 
-template <typename T, int PV, int FX>
+template <typename T, int PW, int FX>  // PW = 1: pointwise problems only (no im2col address arithmetic in the instruction stream)
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
+  constexpr int PV = 0;
   constexpr int BMR = 32;
   // bf16: 72-byte rows put the 8-row-apart column chunks of a 32-lane write group on disjoint bank halves (the transposed
   // row-pair stores become conflict-free); fragments are then read as two 8-byte halves.
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
   const int n0 = tile_n * 128, k0 = tile_k * 128;
   const int Cin = p.C1 + p.C2;
   const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
-  const bool pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
+  const bool pointwise = PW || FX || (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
 
   const int mp = tid & 15;   // row pair inside the 32-row stage
   const int nc = tid >> 4;   // 8-wide column chunk (0..15) of the 128-wide tiles

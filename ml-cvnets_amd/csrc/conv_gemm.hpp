@@ -17,6 +17,11 @@ template <> struct StageGroups<5> { static constexpr int n = 2; static constexpr
 template <typename T, int NF> constexpr int stage_pitch() { return (NF >= 4 ? 128 : (NF >= 2 ? 64 : 32)) + 16 / (int)sizeof(T); }
 
 // Workgroup = 4 waves stacked along M (BM = 128 rows), each wave owns a 32 x (32*NF) output strip.
+__device__ __forceinline__ void lds_f8x(const float* p, float* o) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
 template <typename T, int NF, int BK, int FX>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int BM = 128;
@@ -66,6 +71,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     for (int j = 0; j < 8; ++j) cs1[g][j] = cs2[g][j] = 0.f;
   if (want_stats) {
     for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+  }
+  // FX e_mode 1: the four per-channel vectors of the BatchNorm being back-propagated through, staged once as
+  // est[4][BN] = (invstd, -mean*invstd, scale, shift): the epilogue reads them from LDS (from global memory they cost 8 dependent
+  // 16-byte loads per 8 output elements)
+  float* est = red + 2 * BN;
+  if (FX == 1 && p.e_mode == 1) {
+    for (int i = tid; i < BN; i += 256) {
+      const int n = n0 + i;
+      const bool ok = n < p.N;
+      const float mu = ok ? p.e_stats[n] : 0.f, is = ok ? p.e_stats[p.N + n] : 0.f;
+      est[i] = is;
+      est[BN + i] = -mu * is;
+      est[2 * BN + i] = ok ? p.e_stats[2 * p.N + n] : 0.f;
+      est[3 * BN + i] = ok ? p.e_stats[3 * p.N + n] : 0.f;
+    }
   }
 
   unsigned long long seed = 0;
@@ -252,18 +272,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
             if (FX == 1 && p.e_mode == 1) {
               float a[8];
               v8_unpack(v8_load<T>(reinterpret_cast<const T*>(p.e_aux) + o), a);
-              const float4* st4 = reinterpret_cast<const float4*>(p.e_stats + n);
-              const int q4 = p.N / 4;
-              float mu[8], is[8], sc[8], sh[8];
-              *reinterpret_cast<float4*>(mu) = st4[0]; *reinterpret_cast<float4*>(mu + 4) = st4[1];
-              *reinterpret_cast<float4*>(is) = st4[q4]; *reinterpret_cast<float4*>(is + 4) = st4[q4 + 1];
-              *reinterpret_cast<float4*>(sc) = st4[2 * q4]; *reinterpret_cast<float4*>(sc + 4) = st4[2 * q4 + 1];
-              *reinterpret_cast<float4*>(sh) = st4[3 * q4]; *reinterpret_cast<float4*>(sh + 4) = st4[3 * q4 + 1];
+              const float* ev = est + F0 * 32 + ch * 8;
+              float is[8], mi[8], sc[8], sh[8];
+              lds_f8x(ev, is);
+              lds_f8x(ev + BN, mi);
+              lds_f8x(ev + 2 * BN, sc);
+              lds_f8x(ev + 3 * BN, sh);
               float yh[8];
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 yh[j] = a[j] * sc[j] + sh[j];
-                xh[j] = (a[j] - mu[j]) * is[j];
+                xh[j] = a[j] * is[j] + mi[j];
               }
               act_grad8_mul(v, yh, p.e_act);
             }
@@ -340,7 +359,7 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   constexpr int TILE_ELEMS = (BM + BN) * lds_pitch<T>(BK);
   constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
   constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
-  size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)2 * BN * sizeof(float);
+  size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)(2 + (FX ? 4 : 0)) * BN * sizeof(float);
   auto kern = conv_gemm_kernel<T, NF, BK, FX>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;  // one instantiation = one static

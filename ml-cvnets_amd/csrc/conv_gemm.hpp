@@ -22,13 +22,17 @@ __device__ __forceinline__ void lds_f8x(const float* p, float* o) {
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
-template <typename T, int NF, int BK, int FX>
+// WP = 1 ("wave-private"): single-K-step pointwise problems (Ktot <= BK: the weight tile is resident).  Every wave stages the 32 rows of
+// A it multiplies itself, into its own LDS rows, and the tile loop has NO workgroup barrier: the four waves of a workgroup drift apart,
+// so one wave's epilogue VALU / HBM waits overlap another wave's loads and MFMAs.  (PMC on the BatchNorm-link GEMMs with the
+// cooperative staging: VALUBusy 25 %, MfmaUtil 3 %, LdsUtil 23 %, MemUnitStalled 0 at 7.5 waves per CU — latency, not throughput.)
+template <typename T, int NF, int BK, int FX, int WP = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int BM = 128;
   constexpr int BN = 32 * NF;
   constexpr int CPR = BK / 8;
   constexpr int PITCH = lds_pitch<T>(BK);
-  constexpr int A_IT = (BM * CPR + 255) / 256;
+  constexpr int A_IT = WP ? (32 * CPR) / 64 : (BM * CPR + 255) / 256;
   constexpr int B_IT = (BN * CPR + 255) / 256;
   constexpr int SP = stage_pitch<T, NF>();
   constexpr int TILE_ELEMS = (BM + BN) * PITCH;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   const T* __restrict__ wgt = reinterpret_cast<const T*>(p.wgt);
   T* __restrict__ out = reinterpret_cast<T*>(p.out);
 
-  const int ccol = tid % CPR;  // this thread's 8-wide K chunk column inside a tile row (same for all its chunks)
+  const int ccol = tid % CPR;  // this thread's 8-wide K chunk column inside a tile row (same for all its chunks; WP: lane % CPR == tid % CPR)
   const bool pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
   const bool want_stats = p.stats_part != nullptr;
   // FX = 1: A operand plain or act(c0*a + c1) (run-time), epilogue modes, links;  FX = 2: A operand = c0*a + c1*a2 + c2 (two sources)
@@ -88,6 +92,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     }
   }
 
+  // bias of this lane's column in every accumulator fragment, loaded ONCE: a (conditional) load inside the epilogue is followed by
+  // s_waitcnt vmcnt(0), which also drains the next M tile's operand loads requested just before the epilogue — the prefetch then
+  // overlaps nothing and every tile pays a full memory latency up front
+  float bias_r[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int n = n0 + f * 32 + (lane & 31);
+    bias_r[f] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+  }
+
   unsigned long long seed = 0;
   if (p.drop_p > 0.f) seed = *p.seed;
   const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -114,14 +128,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     }
   }
 
+  if (WP) __syncthreads();  // the resident weight tile (and the staged per-channel vectors) are visible to every wave; no barrier after this
+
   auto decode_rows = [&](int m0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      int q = tid + i * 256;
-      int r = q / CPR;
+      int q = WP ? (tid & 63) + i * 64 : tid + i * 256;
+      int r = WP ? (tid >> 6) * 32 + q / CPR : q / CPR;
       a_row[i] = r;
       int m = m0 + r;
-      a_ok[i] = (q < BM * CPR) && (m < p.M);
+      a_ok[i] = (WP || q < BM * CPR) && (m < p.M);
       if (pointwise) {
         a_b[i] = 0; a_h[i] = 0; a_w[i] = m;  // linear pixel index
       } else {
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   auto store_tiles = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      int q = tid + i * 256;
+      int q = WP ? 0 : tid + i * 256;
       if (FX && a_mode) {
         // rows beyond M / K chunks beyond Ktot only feed accumulator rows that are never stored (or meet zero weights): no masking needed
         if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, xf_apply<T>(ra[i], ra2[FX == 2 ? i : 0], kc, a_mode, p.a_xf.act, true));
@@ -208,9 +224,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     for (int f = 0; f < NF; ++f) acc[f] = acc_zero();
 
     for (int k0 = 0; k0 < p.Ktot; k0 += BK) {
-      __syncthreads();  // previous tile (or previous epilogue's staging) fully consumed
+      if (WP) wave_lds_sync(); else __syncthreads();  // previous tile (or previous epilogue's staging) fully consumed
       store_tiles();
-      __syncthreads();
+      if (WP) wave_lds_sync(); else __syncthreads();
       if (k0 + BK < p.Ktot) load_tiles(k0 + BK);  // prefetch next K tile into registers under the MFMAs
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 16) {
@@ -240,8 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
       static_for<0, GW>([&](auto fi) {
         constexpr int fl = decltype(fi)::value;
         constexpr int f = F0 + fl;
-        const int n = n0 + f * 32 + (lane & 31);
-        const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+        const float bias = bias_r[f];
 #pragma unroll
         for (int r = 0; r < 16; ++r) stg[acc_row(r, lane) * SP + fl * 32 + (lane & 31)] = from_f<T>(acc[f][r] + bias);
       });
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 // =============================================================================================
 // host-side dispatch
 // =============================================================================================
-template <typename T, int NF, int BK, int FX>
+template <typename T, int NF, int BK, int FX, int WP = 0>
 static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   constexpr int BM = 128, BN = 32 * NF;
   ConvGemmParams p = p0;
@@ -360,7 +375,7 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
   constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
   size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)(2 + (FX ? 4 : 0)) * BN * sizeof(float);
-  auto kern = conv_gemm_kernel<T, NF, BK, FX>;
+  auto kern = conv_gemm_kernel<T, NF, BK, FX, WP>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;  // one instantiation = one static
     if (!attr_set) {
@@ -374,8 +389,17 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int BK, int FX>
+template <typename T, int BK, int FX, int WP = 0>
 static int dispatch_conv_gemm_nf(const ConvGemmParams& p, int nf, hipStream_t st) {
+  if (WP) {
+    switch (nf) {
+      case 1: return launch_conv_gemm<T, 1, BK, FX, WP>(p, st);
+      case 2: return launch_conv_gemm<T, 2, BK, FX, WP>(p, st);
+      case 3: return launch_conv_gemm<T, 3, BK, FX, WP>(p, st);
+      case 4: return launch_conv_gemm<T, 4, BK, FX, WP>(p, st);
+      default: return launch_conv_gemm<T, 5, BK, FX, WP>(p, st);
+    }
+  }
   switch (nf) {
     case 1: return launch_conv_gemm<T, 1, BK, FX>(p, st);
     case 2: return launch_conv_gemm<T, 2, BK, FX>(p, st);

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   constexpr int B_IT = (BN * CPR + 255) / 256;
   constexpr int SP = stage_pitch<T, NF>();
   constexpr int TILE_ELEMS = (BM + BN) * PITCH;
-  constexpr int STAGE_ELEMS = 4 * 32 * SP;
+  // WP: a wave's 32 private A rows are dead once its MFMAs are done, so its epilogue staging can live there (no extra LDS)
+  constexpr bool STG_ALIAS = WP && PITCH >= SP;
+  constexpr int STAGE_ELEMS = STG_ALIAS ? 0 : 4 * 32 * SP;
   constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
   using SG = StageGroups<NF>;
 
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  T* stg = As + TILE_ELEMS + wave * (32 * SP);  // per-wave PRIVATE output staging: the epilogue needs only wave-level ordering
+  T* stg = STG_ALIAS ? As + wave * (32 * PITCH) : As + TILE_ELEMS + wave * (32 * SP);  // per-wave PRIVATE output staging: the epilogue needs only wave-level ordering
   // XCD-contiguous work order, N tile fastest: the workgroups that share an M tile (one per N tile) get consecutive logical ids and so
   // run on the same XCD — the A rows are fetched into ONE L2 instead of once per XCD (hardware: linear workgroup id b -> XCD b % 8)
   const int bid_ = xcd_chunk_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
@@ -116,21 +118,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
   // single K step (pointwise convs with Cin <= BK): the weight tile is staged ONCE per workgroup, not once per M tile
   const bool b_resident = p.Ktot <= BK;
   if (b_resident) {
-    const int k = ccol * 8;
-    if (FX && a_mode) coef8_load(kc, p.a_xf, k, k < p.Ktot);
+    if (FX && a_mode) coef8_load(kc, p.a_xf, ccol * 8, ccol * 8 < p.Ktot);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       int q = tid + i * 256;
       int n = n0 + q / CPR;
+      const int k = (q % CPR) * 8;  // (== ccol * 8 when 256 % CPR == 0)
       V8<T> v = v8_zero<T>();
       if (q < BN * CPR && n < p.N && k < p.Ktot) v = v8_load<T>(wgt + (size_t)n * p.Ktot + k);
-      if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + ccol * 8, v);
+      if (q < BN * CPR) v8_store<T>(Bs + (q / CPR) * PITCH + k, v);
     }
   }
 
   if (WP) __syncthreads();  // the resident weight tile (and the staged per-channel vectors) are visible to every wave; no barrier after this
 
+  int wp_m0 = 0;  // WP: first row of the tile whose A rows are in flight; row / chunk of a load are recomputed from (lane, i), not stored
   auto decode_rows = [&](int m0) __attribute__((always_inline)) {
+    if (WP) { wp_m0 = m0; return; }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int q = WP ? (tid & 63) + i * 64 : tid + i * 256;
@@ -159,7 +163,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     const T* s = src1; int cs = p.C1; int cc = c;
     if (!FX && c >= p.C1) { s = src2; cs = p.C2; cc = c - p.C1; }  // FX: single source; predicated loads need a valid base
     if (FX && a_mode && !b_resident) coef8_load(kc, p.a_xf, k, kok);
-    if (FX) {  // pointwise by construction; clamped loads, no mask: rows >= M / K chunks >= Ktot never reach a stored value
+    if (WP) {  // single K step, pointwise, one source; branch-free clamped loads
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int q = (tid & 63) + i * 64;
+        const int m = wp_m0 + (tid >> 6) * 32 + q / CPR, c8 = (q % CPR) * 8;
+        ra[i] = v8_load_clamped<T>(src1, (size_t)m * p.C1 + c8, m < p.M && c8 < p.Ktot);
+      }
+    } else if (FX) {  // pointwise by construction; clamped loads, no mask: rows >= M / K chunks >= Ktot never reach a stored value
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) ra[i] = v8_load_clamped<T>(s, (size_t)a_w[i] * cs + cc, a_ok[i] && kok);
       if (FX == 2) {
@@ -193,15 +204,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     }
   };
   auto store_tiles = [&]() __attribute__((always_inline)) {
+    if (WP) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int q = (tid & 63) + i * 64;
+        const int r = (tid >> 6) * 32 + q / CPR, c8 = (q % CPR) * 8;
+        T* dst = As + r * PITCH + c8;
+        // plain operand: rows >= M / chunks >= Ktot are zeroed here (they met clamped addresses); transformed operand: such rows only
+        // feed accumulator rows that are never stored and chunks >= Ktot meet zero weights
+        if (FX && a_mode) v8_store<T>(dst, xf_apply<T>(ra[i], ra2[FX == 2 ? i : 0], kc, a_mode, p.a_xf.act, true));
+        else v8_store<T>(dst, v8_mask(ra[i], wp_m0 + r < p.M && c8 < p.Ktot));
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      int q = WP ? 0 : tid + i * 256;
+      int q = tid + i * 256;
       if (FX && a_mode) {
         // rows beyond M / K chunks beyond Ktot only feed accumulator rows that are never stored (or meet zero weights): no masking needed
         if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, xf_apply<T>(ra[i], ra2[FX == 2 ? i : 0], kc, a_mode, p.a_xf.act, true));
       } else {
         if (q < BM * CPR) v8_store<T>(As + a_row[i] * PITCH + ccol * 8, ra[i]);
       }
+    }
     }
     if (!b_resident) {
 #pragma unroll
@@ -248,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 
     // ---- epilogue: accumulators -> (bias) -> per-wave LDS staging -> coalesced 16 B/lane rows with the fused
     //      activation / act-grad / dropout / residual / BatchNorm statistics ----
+    if (STG_ALIAS) wave_lds_sync();  // this wave's fragment reads of its A rows are done before the staging overwrites them
     static_for<0, SG::n>([&](auto gi) {
       constexpr int g = decltype(gi)::value;
       constexpr int F0 = SG::start[g], GW = SG::width[g];
@@ -372,7 +397,7 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   int gx = p.m_tiles < cap ? p.m_tiles : cap;
   dim3 grid(gx, n_tiles);
   constexpr int TILE_ELEMS = (BM + BN) * lds_pitch<T>(BK);
-  constexpr int STAGE_ELEMS = 4 * 32 * stage_pitch<T, NF>();
+  constexpr int STAGE_ELEMS = (WP && lds_pitch<T>(BK) >= stage_pitch<T, NF>()) ? 0 : 4 * 32 * stage_pitch<T, NF>();
   constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
   size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)(2 + (FX ? 4 : 0)) * BN * sizeof(float);
   auto kern = conv_gemm_kernel<T, NF, BK, FX, WP>;
@@ -410,10 +435,10 @@ static int dispatch_conv_gemm_nf(const ConvGemmParams& p, int nf, hipStream_t st
 }
 
 // choose the N tiling: fewest padded columns, then fewest tiles
-static int choose_nf(int N) {
+static int choose_nf_capped(int N, int cap) {
   static const int cand[5] = {1, 2, 3, 4, 5};
-  int best = 4, best_cost = 1 << 30;
-  for (int i = 0; i < 5; ++i) {
+  int best = cap < 4 ? cap : 4, best_cost = 1 << 30;
+  for (int i = 0; i < 5 && cand[i] <= cap; ++i) {
     int bn = 32 * cand[i];
     int tiles = (N + bn - 1) / bn;
     int cost = tiles * bn * 16 + tiles;  // padded width dominates, tile count breaks ties
@@ -421,3 +446,4 @@ static int choose_nf(int N) {
   }
   return best;
 }
+static int choose_nf(int N) { return choose_nf_capped(N, 5); }

@@ -85,6 +85,14 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   if (dtype == CVH_DT_BF16 && gemm_big_eligible(p)) return launch_gemm_big(p, st);  // transformer-sized linears (ViT-B / CLIP)
   const int nf = choose_nf(N);
   const bool bk64 = p.Ktot >= 64;
+  if (dtype == CVH_DT_BF16 && src2 == nullptr && KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.Ktot <= 64 && p.M >= 4096 &&
+      !cvh_tune_get(CVH_TUNE_NO_WAVE_PRIVATE)) {
+    // Plain pointwise GEMMs whose whole K is ONE step (the 1x1 convs of the high-resolution stages): weights resident in LDS, every wave
+    // streams its own rows, no workgroup barrier in the tile loop (conv_gemm.hpp, WP): 3.5 -> 4.4 TB/s on [4.2M x 64] x [64 x 256].
+    // (Measured and not adopted: the same with K tiles of 128 / 160 for the d = 96 ... 160 transformer linears — 8-10 operand vectors
+    // per lane in flight across the epilogue spill, the N tile has to shrink to 64-96 columns, and the step time does not move.)
+    return p.Ktot <= 32 ? dispatch_conv_gemm_nf<bf16_t, 32, 0, 1>(p, nf, st) : dispatch_conv_gemm_nf<bf16_t, 64, 0, 1>(p, nf, st);
+  }
   if (dtype == CVH_DT_BF16) {
     // narrow-output pointwise GEMMs whose K is a little over one 64-wide step (the channel-concat dX of a 1x1 expansion conv:
     // K = 5 * Cin = 80 / 160): a 128-wide K tile keeps the weights resident for K <= 128 and halves the barriers per byte

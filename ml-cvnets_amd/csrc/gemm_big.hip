@@ -23,6 +23,7 @@ constexpr int STG_PITCH = 64 + 8;            // bf16 elements per staged output 
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];  // zero-initialised: source of out-of-range rows / chunks
 
 __device__ __forceinline__ void glds16(const bf16_t* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
@@ -38,7 +39,11 @@ __device__ __forceinline__ Frag<bf16_t> frag_swz(const unsigned char* tile, int 
 // WM = wave rows: tile = (64*WM) x 128, 2*WM waves.  WM = 2: 128x128, 64 KB LDS, 2 workgroups per CU.  WM = 4: 256x128, 96 KB LDS, one
 // 8-wave workgroup per CU — same waves per CU, but 1.33x the MFMA work per byte brought into LDS (the kernel is bound by the bytes
 // it can keep in flight towards LDS: ~1.5 us of L2/HBM latency x 2 tile buffers).
-template <int WM>
+// RAGGED: N need not be a multiple of 128 nor K of 64 (only of 8): 16-byte chunks past the end of a row of A / of the weight, and weight
+// rows past N, are fetched from a zero line; output columns past N are not stored.  Opens the direct-to-LDS pipeline (no staging VGPRs,
+// no VALU between HBM and the MFMA operands) to the d = 144 ... 720 transformer linears of MobileViT, which the register-staged
+// conv_gemm runs at 1.5-2.4 TB/s (every 64-wide K step exposes a memory latency behind two barriers).
+template <int WM, bool RAGGED>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(ConvGemmParams p) {
   constexpr int BM = 64 * WM;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int K = p.Ktot, N = p.N, M = p.M;
-  const int NT = N / BN;
+  const int NT = (N + BN - 1) / BN;
   const int total = p.m_tiles * NT;
   const int L = xcd_chunk_id(blockIdx.x, total);
   const int mt = L / NT, nt = L - mt * NT;
@@ -58,6 +63,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
   // this lane's 4 + 4 chunks per K step: wave-instruction i = wave*4 + j covers tile rows [8i, 8i+8), lane -> (row, LDS slot)
   const bf16_t* ga[4];
   const bf16_t* gb[4];
+  int ka[4], kb[4];      // RAGGED: column (within a K step) of this lane's chunk; weight rows past N start beyond every K
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (wave * 4 + j) * 8 + (lane >> 3);
@@ -65,20 +71,24 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
     int am = m0 + row;
     if (am > M - 1) am = M - 1;  // rows past M: read a valid row, the result is never stored
     ga[j] = A + (size_t)am * K + c * 8;
+    ka[j] = c * 8;
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int row = (wave * NB + j) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
-    gb[j] = Wp + (size_t)(n0 + row) * K + c * 8;
+    const bool row_ok = !RAGGED || n0 + row < N;
+    gb[j] = Wp + (size_t)(row_ok ? n0 + row : 0) * K + c * 8;
+    kb[j] = row_ok ? c * 8 : (1 << 30);
   }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_line);
   auto issue = [&](int kt, int buf) {
     unsigned char* a_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024;
     unsigned char* b_dst = smem + buf * BUF_BYTES + A_BYTES + (wave * NB) * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(ga[j] + kt * BK, a_dst + j * 1024);
+    for (int j = 0; j < 4; ++j) glds16((!RAGGED || kt * BK + ka[j] < K) ? ga[j] + kt * BK : zero, a_dst + j * 1024);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) glds16(gb[j] + kt * BK, b_dst + j * 1024);
+    for (int j = 0; j < NB; ++j) glds16((!RAGGED || kt * BK + kb[j] < K) ? gb[j] + kt * BK : zero, b_dst + j * 1024);
   };
 
   f32x16_t acc[2][2];
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
 
-  const int KT = K / BK;
+  const int KT = (K + BK - 1) / BK;
   issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     const int n = n0 + wc * 64 + tj * 32 + (lane & 31);
-    const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+    const float bias = (p.bias != nullptr && (!RAGGED || n < N)) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -130,25 +140,34 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
   wave_lds_sync();
   const int ch = lane & 7;
   const int ncol = n0 + wc * 64 + ch * 8;
+  // the epilogue's own HBM operands for all 8 passes are requested first (the accumulators are dead: registers are free), so their
+  // latency is paid once per tile, not once per pass
+  const bf16_t* agp = reinterpret_cast<const bf16_t*>(p.actgrad_aux);
+  const bf16_t* rsp = reinterpret_cast<const bf16_t*>(p.residual);
+  V8<bf16_t> agr[8], rsr[8];
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int m = m0 + wr * 64 + pass * 8 + (lane >> 3);
+    const bool ok = m < M && (!RAGGED || ncol < N);
+    const size_t o = (size_t)m * N + ncol;
+    agr[pass] = v8_load_clamped<bf16_t>(agp ? agp : out, o, ok && agp != nullptr);
+    rsr[pass] = v8_load_clamped<bf16_t>(rsp ? rsp : out, o, ok && rsp != nullptr);
+  }
 #pragma unroll
   for (int pass = 0; pass < 8; ++pass) {
     const int row = pass * 8 + (lane >> 3);
     const int m = m0 + wr * 64 + row;
-    if (m < M) {
+    if (m < M && (!RAGGED || ncol < N)) {
       const size_t o = (size_t)m * N + ncol;
       V8<bf16_t> pv = v8_load<bf16_t>(stg + row * STG_PITCH + ch * 8);
       if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
       float v[8];
       v8_unpack(pv, v);
-      if (p.act != CVH_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], p.act);
-      }
+      if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
       if (p.actgrad_aux) {  // backward through the producer's activation: v *= act'(pre-activation of the layer below)
         float a[8];
-        v8_unpack(v8_load<bf16_t>(reinterpret_cast<const bf16_t*>(p.actgrad_aux) + o), a);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= act_grad(a[j], p.actgrad_act);
+        v8_unpack(agr[pass], a);
+        act_grad8_mul(v, a, p.actgrad_act);
       }
       if (p.drop_p > 0.f) {
 #pragma unroll
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
       }
       if (p.residual) {
         float rr[8];
-        v8_unpack(v8_load<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + o), rr);
+        v8_unpack(rsr[pass], rr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rr[j];
       }
@@ -170,26 +189,32 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
 bool gemm_big_eligible(const ConvGemmParams& p) {
   if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
   const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
-  return linear && p.M >= 2048 && p.N >= 256 && (p.N % BN) == 0 && p.Ktot >= 256 && (p.Ktot % BK) == 0 && p.stats_part == nullptr &&
-         p.sc_s == 0;
+  if (!linear || p.M < 2048 || p.stats_part != nullptr || p.sc_s != 0) return false;
+  if (p.N >= 256 && (p.N % BN) == 0 && p.Ktot >= 256 && (p.Ktot % BK) == 0) return true;  // ViT-B / CLIP sized
+  // ragged tiles: measured against conv_gemm on the MobileViT linears (M = 65 k ... 1 M rows): ahead for wide outputs
+  // (144 -> 432: 780 -> 620 us, 240 -> 720: 125 -> 58 us), level or behind for N <= 288 where conv_gemm's 96 / 160-column tiles fit exactly
+  return p.N >= 384 && (p.N % 8) == 0 && p.Ktot > 64 && (p.Ktot % 8) == 0;
 }
 
 int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
   ConvGemmParams p = p0;
-  if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 2 && p.M >= 8192) {  // 256 x 128 tiles, one 8-wave workgroup per CU
+  const bool ragged = (p.N % BN) != 0 || (p.Ktot % BK) != 0;
+  const int n_tiles = (p.N + BN - 1) / BN;
+  if (!ragged && cvh_tune_get(CVH_TUNE_BIG_GEMM) == 2 && p.M >= 8192) {  // 256 x 128 tiles, one 8-wave workgroup per CU
     p.m_tiles = (p.M + 255) / 256;
     constexpr int smem = 2 * (256 + 128) * BK * 2;  // 96 KB
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt128_kernel<4>, dim3(p.m_tiles * (p.N / BN)), dim3(512), smem, st, p);
+    hipLaunchKernelGGL((gemm_nt128_kernel<4, false>), dim3(p.m_tiles * n_tiles), dim3(512), smem, st, p);
   } else {
     p.m_tiles = (p.M + 127) / 128;
     constexpr int smem = 2 * BUF_BYTES;  // 64 KB: two workgroups per CU
-    hipLaunchKernelGGL(gemm_nt128_kernel<2>, dim3(p.m_tiles * (p.N / BN)), dim3(256), smem, st, p);
+    if (ragged) hipLaunchKernelGGL((gemm_nt128_kernel<2, true>), dim3(p.m_tiles * n_tiles), dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((gemm_nt128_kernel<2, false>), dim3(p.m_tiles * n_tiles), dim3(256), smem, st, p);
   }
   CVH_CHECK_LAUNCH();
   return 0;
@@ -208,7 +233,6 @@ int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
 //   * rows past the end of the split read a zero line, so any M works; splits over M fill the chip, gemm_dw_reduce_kernel sums them.
 // =============================================================================================
 namespace {
-__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];  // zero-initialised: source of out-of-range rows
 typedef short tr_v4s __attribute__((ext_vector_type(4)));
 typedef short tr_v8s __attribute__((ext_vector_type(8)));
 

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
     for (int f = 0; f < NFC; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[f][r] *= alpha;
-    __syncthreads();  // P visible (wave-local data, workgroup barrier keeps the control flow uniform)
+    wave_lds_sync();  // P is wave-private: only this wave reads it back (a workgroup barrier here made every wave wait for the slowest softmax)
     // O^T[c][q] += sum_key V[key][c] * P^T[key][q]
 #pragma unroll
     for (int kk = 0; kk < KB; kk += 16) {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
       }
       store_acc_transposed<T>(dSs, PP, f * 32, ds, lane);
     }
-    __syncthreads();
+    wave_lds_sync();  // dS is wave-private
     // dQ^T[c][q] += sum_key K[key][c] * dS^T[key][q]
 #pragma unroll
     for (int kk = 0; kk < KB; kk += 16) {
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
     }
     store_acc_natural<T>(PTs, PT, 0, 0, pt, lane);    // PTs[key][q]
     store_acc_natural<T>(dSTs, PT, 0, 0, dsv, lane);  // dSTs[key][q]
-    __syncthreads();
+    wave_lds_sync();  // P^T and dS^T are wave-private
     // dV[key][c] += sum_q P^T[key][q] dO[q][c] ;  dK[key][c] += sum_q dS^T[key][q] Qs[q][c]
 #pragma unroll
     for (int kk = 0; kk < QB; kk += 16) {

@@ -160,7 +160,7 @@ def dominant_kernel_probe(dtype, shapes):
         if worst is None or ms > worst[0]:
             worst = (ms, f"M={M} N={N} K={Ktot}")
         del dy, x, x2, dw, scr
-    return {"kernel": "gemm_tn_kernel<bf16_t, 0, 0> / gemm_tn_skinny_kernel (+ split reduction): every plain dW GEMM dY^T x im2col(X) of one training step",
+    return {"kernel": "gemm_tn_kernel<bf16_t, *, 0> / gemm_tn_skinny_kernel / gemm_tn128_kernel (+ split reduction): every plain dW GEMM dY^T x im2col(X) of one training step",
             "launches_per_step": n, "avg_ms": round(total_ms / max(n, 1), 4), "total_ms_per_step": round(total_ms, 3),
             "algorithmic_bytes": int(total_bytes / max(n, 1)), "achieved_GBps": round(total_bytes / (total_ms * 1e-3) / 1e9, 1),
             "longest_launch": {"ms": round(worst[0], 4), "shape": worst[1]} if worst else None}

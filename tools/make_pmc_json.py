@@ -3,8 +3,8 @@
 
     python tools/make_pmc_json.py <pmc FETCH_SIZE dir> <pmc WRITE_SIZE dir> <kernel-trace dir> <batch> <tag> > profiles/pmc_traffic.json
 
-HBM bytes per step and per launch of the dominant kernel class (every plain dW GEMM: gemm_tn_kernel<bf16_t, 0, 0> and
-gemm_tn_skinny_kernel<...>) from the two PMC passes — units and the gfx950 FETCH_SIZE doubling as in tools/pmc_summary.py — and the
+HBM bytes per step and per launch of the dominant kernel class (every plain dW GEMM: gemm_tn_kernel<bf16_t, *, 0>,
+gemm_tn_skinny_kernel<...>, gemm_tn128_kernel<...>) from the two PMC passes — units and the gfx950 FETCH_SIZE doubling as in tools/pmc_summary.py — and the
 class's average launch duration from the kernel trace of the bench command."""
 import collections
 import csv
@@ -23,7 +23,7 @@ def counter(d, name):
 
 
 def dominant(n):
-    return "gemm_tn_kernel<bf16_t, 0, 0>" in n or "gemm_tn_skinny_kernel" in n
+    return "gemm_tn_kernel<bf16_t, 0, 0>" in n or "gemm_tn_kernel<bf16_t, 1, 0>" in n or "gemm_tn_skinny_kernel" in n or "gemm_tn128_kernel" in n
 
 
 fetch, cnt = counter(sys.argv[1], "FETCH_SIZE")
@@ -42,7 +42,7 @@ print(json.dumps({
               f"--no-cpu-baseline` (batch {sys.argv[4]}, 1x MI355X, {sys.argv[5]} build); FETCH_SIZE doubled per the gfx950 correction of "
               f"MI355X_MICROARCH.md, WRITE_SIZE as exported; tools/make_pmc_json.py",
     "step": {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr, "images": int(sys.argv[4]), "steps_profiled": steps},
-    "dominant_kernel": {"name": "gemm_tn_kernel<bf16_t, 0, 0> + gemm_tn_skinny_kernel<...> (every plain dW GEMM of the step)",
+    "dominant_kernel": {"name": "gemm_tn_kernel<bf16_t, *, 0> + gemm_tn_skinny_kernel<...> + gemm_tn128_kernel<...> (every plain dW GEMM of the step)",
                         "launches_per_step": dk_n / steps, "bytes_per_launch": dk_b / max(dk_n, 1),
                         "rocprof_avg_ms": dur / max(n, 1), "rocprof_launches": n},
 }, indent=1))

@@ -31,6 +31,7 @@ extern "C" {
 #define CVH_ACT_NONE 0
 #define CVH_ACT_SILU 1 /* nn.SiLU  — cvnets/layers/activation/swish.py */
 #define CVH_ACT_GELU 2 /* nn.GELU (erf) — cvnets/layers/activation/gelu.py:11-18 */
+#define CVH_ACT_RELU 3 /* nn.ReLU — cvnets/layers/activation/relu.py (segmentation heads: model.activation.name = relu) */
 
 /* ---- layout / dtype plumbing ------------------------------------------------------------------ */
 /* NCHW float32 -> NHWC `dtype`, channels zero-padded to Cp (Cp % 8 == 0).  Replaces the implicit
@@ -208,6 +209,13 @@ int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const u
 int cvh_drop_path(int dtype, const void* x, const void* res, void* y, long long rows, int C, int ph, int pw, int H, int W, float p,
                   const unsigned long long* seed, unsigned int stream_id, void* stream);
 int cvh_seed_advance(unsigned long long* seed, void* stream);
+/* nn.Dropout2d (cvnets/layers/dropout.py:32-50): drops whole channels per sample, NHWC x[B][HW][C]; keep(b, c) is regenerated from
+ * (*seed, stream_id), so the backward pass is the same call on dY. */
+int cvh_dropout2d(int dtype, const void* x, void* y, int B, int HW, int C, float p, const unsigned long long* seed, unsigned int stream_id,
+                  void* stream);
+/* torch.cat(dim=1) of n <= 8 NHWC tensors parts[i][rows][channels[i]] into whole[rows][sum channels] (split == 0), or the inverse copy
+ * (split != 0: gradient of the concat).  ASPP branch concat, cvnets/modules/aspp_block.py:118-121.  `parts` / `channels` are HOST arrays. */
+int cvh_cat_channels(int dtype, void* const* parts, const int* channels, int n, void* whole, long long rows, int split, void* stream);
 int cvh_add(int dtype, const void* a, const void* b, void* y, long long n, void* stream);
 
 /* F.interpolate(mode="bilinear") for feature maps that are not a multiple of the patch: align_corners=False in

@@ -12,6 +12,7 @@
 #define CVH_ACT_NONE 0
 #define CVH_ACT_SILU 1
 #define CVH_ACT_GELU 2
+#define CVH_ACT_RELU 3
 
 struct bf16_t {
   uint16_t v;
@@ -146,6 +147,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float act_fwd(float x, int act) {
   if (act == CVH_ACT_SILU) return x * sigmoidf_(x);
   if (act == CVH_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));  // exact erf GELU
+  if (act == CVH_ACT_RELU) return fmaxf(x, 0.0f);
   return x;
 }
 __device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
@@ -158,6 +160,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
     float pdf = 0.3989422804014327f * fast_exp(-0.5f * x * x);
     return cdf + x * pdf;
   }
+  if (act == CVH_ACT_RELU) return x > 0.0f ? 1.0f : 0.0f;
   return 1.0f;
 }
 // 8-wide forms: ONE (wave-uniform) dispatch on `act` per vector instead of one per element — the per-element scalar branches
@@ -169,6 +172,9 @@ __device__ __forceinline__ void act_fwd8(float* v, int act) {
   } else if (act == CVH_ACT_GELU) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+  } else if (act == CVH_ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
   }
 }
 // g[j] *= act'(x[j])
@@ -186,6 +192,9 @@ __device__ __forceinline__ void act_grad8_mul(float* g, const float* x, int act)
       const float pdf = 0.3989422804014327f * fast_exp(-0.5f * x[j] * x[j]);
       g[j] *= cdf + x[j] * pdf;
     }
+  } else if (act == CVH_ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = x[j] > 0.0f ? g[j] : 0.0f;
   }
 }
 

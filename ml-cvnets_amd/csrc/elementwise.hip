@@ -663,6 +663,51 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_
     y[i] = from_f<T>(to_f<T>(x[i]) * dropout_scale(seed, stream_id, i, p, inv_keep));
 }
 
+// Dropout2d (cvnets/layers/dropout.py:32-50 -> nn.Dropout2d): whole channels of a sample are dropped; keep(b, c) comes from the same
+// counter-based generator (element index = b*C + c), so the backward pass (the same kernel on dY) regenerates the mask.  NHWC, C % 8 == 0.
+template <typename T>
+__global__ void dropout2d_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n8, int HW, int C, float p,
+                                 const unsigned long long* __restrict__ seedp, unsigned int stream_id) {
+  const unsigned long long seed = *seedp;
+  const float inv_keep = 1.0f / (1.0f - p);
+  const int c8n = C / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % c8n);
+    const size_t b = i / ((size_t)c8n * HW);
+    float f[8];
+    v8_unpack(v8_load<T>(x + i * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= dropout_scale(seed, stream_id, b * C + c8 * 8 + j, p, inv_keep);
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(y + i * 8, o);
+  }
+}
+
+// channel concat of up to 8 NHWC tensors (torch.cat(dim=1) of the ASPP branches, cvnets/modules/aspp_block.py:118-121) and its inverse
+// (the backward pass: the gradient of the concat is split back into the branches)
+struct CatParams {
+  void* ptr[8];
+  int c8_end[8];  // exclusive prefix sums of C_i / 8
+  int n;
+};
+template <typename T, bool SPLIT>
+__global__ void cat_channels_kernel(CatParams cp, T* __restrict__ whole, size_t rows, int c8_total) {
+  const size_t n8 = rows * c8_total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % c8_total);
+    const size_t r = i / c8_total;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += (k < cp.n - 1 && c8 >= cp.c8_end[k]) ? 1 : 0;
+    const int c8_begin = s ? cp.c8_end[s - 1] : 0;
+    const int cs8 = cp.c8_end[s] - c8_begin;
+    T* part = reinterpret_cast<T*>(cp.ptr[s]) + (r * cs8 + (c8 - c8_begin)) * 8;
+    if (SPLIT) v8_store<T>(part, v8_load<T>(whole + i * 8));
+    else v8_store<T>(whole + i * 8, v8_load<T>(part));
+  }
+}
+
 // elementwise a + b (residual adds outside GEMM epilogues)
 template <typename T>
 __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t n8) {
@@ -990,6 +1035,37 @@ extern "C" int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, 
 extern "C" int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned int stream_id,
                            void* stream) {
   DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (size_t)n, p, seed, stream_id);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_dropout2d(int dtype, const void* x, void* y, int B, int HW, int C, float p, const unsigned long long* seed,
+                             unsigned int stream_id, void* stream) {
+  if ((C % 8) != 0 || p < 0.f || p >= 1.f || seed == nullptr) return -2;
+  const size_t n8 = (size_t)B * HW * (C / 8);
+  if (n8 == 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dropout2d_kernel<T>), dim3(grid_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, n8, HW, C, p, seed, stream_id);)
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int cvh_cat_channels(int dtype, void* const* parts, const int* channels, int n, void* whole, long long rows, int split, void* stream) {
+  if (n < 1 || n > 8 || rows < 0) return -2;
+  CatParams cp;
+  cp.n = n;
+  int acc = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (i < n) {
+      if ((channels[i] % 8) != 0 || channels[i] <= 0 || parts[i] == nullptr) return -2;
+      acc += channels[i] / 8;
+      cp.ptr[i] = parts[i];
+    } else {
+      cp.ptr[i] = nullptr;
+    }
+    cp.c8_end[i] = acc;
+  }
+  const size_t n8 = (size_t)rows * acc;
+  if (n8 == 0) return 0;
+  if (split) { DISPATCH_T(dtype, hipLaunchKernelGGL((cat_channels_kernel<T, true>), dim3(grid_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, cp, (T*)whole, (size_t)rows, acc);) }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((cat_channels_kernel<T, false>), dim3(grid_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, cp, (T*)whole, (size_t)rows, acc);) }
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -58,6 +58,8 @@ SIGNATURES = {
     "cvh_drop_path": [I, P, P, P, L, I, I, I, I, I, F, P, U, P],
     "cvh_mix_batch": [I, P, P, I, I, I, I, I, F, I, I, I, I, P],
     "cvh_add": [I, P, P, P, L, P],
+    "cvh_dropout2d": [I, P, P, I, I, I, F, P, U, P],
+    "cvh_cat_channels": [I, P, P, I, P, L, I, P],
     "cvh_rows_gather_idx": [I, P, P, P, I, I, I, P],
     "cvh_l2norm_fwd": [I, P, P, P, I, I, F, P],
     "cvh_l2norm_bwd": [I, P, P, P, P, I, I, F, P],

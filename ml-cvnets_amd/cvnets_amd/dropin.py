@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 from torch import nn
 
-from . import clip, layers, models, modules
+from . import clip, layers, models, modules, segmentation
 
 # reference class name -> cvnets_amd class (matched by name AND by defining package to avoid swapping foreign classes)
 _BY_NAME = {
@@ -48,6 +48,15 @@ _BY_NAME = {
     "CLIP": clip.CLIP,
     # parameter-free leaves: swapped too, so that a swapped model holds no reference class at all (it can then be pickled / deep-copied /
     # shipped to a process that does not have the reference tree, and `act_code` sees the mirrors' own types)
+    "SegEncoderDecoder": segmentation.SegEncoderDecoder,
+    "DeeplabV3": segmentation.DeeplabV3,
+    "ASPP": segmentation.ASPP,
+    "ASPPConv2d": segmentation.ASPPConv2d,
+    "ASPPPooling": segmentation.ASPPPooling,
+    "Dropout2d": layers.Dropout2d,
+    "AdaptiveAvgPool2d": layers.AdaptiveAvgPool2d,
+    "UpSample": layers.UpSample,
+    "ReLU": layers.ReLU,
     "StochasticDepth": layers.StochasticDepth,
     "Swish": layers.Swish,
     "GELU": layers.GELU,

@@ -83,7 +83,14 @@ class Identity(nn.Module):
         return x
 
 
-ACT_FN_REGISTRY = {"swish": Swish, "gelu": GELU}
+class ReLU(nn.ReLU):
+    """cvnets/layers/activation/relu.py (the activation of the segmentation heads: model.activation.name = relu)"""
+
+    def __init__(self, inplace: Optional[bool] = False, *args, **kwargs) -> None:
+        super().__init__(inplace=bool(inplace))
+
+
+ACT_FN_REGISTRY = {"swish": Swish, "gelu": GELU, "relu": ReLU}
 
 
 def build_activation_layer(opts=None, act_type: Optional[str] = None, inplace: Optional[bool] = None, *args, **kwargs) -> nn.Module:
@@ -102,6 +109,8 @@ def act_code(m: Optional[nn.Module]) -> int:
         return ops.ACT_SILU
     if isinstance(m, nn.GELU):
         return ops.ACT_GELU
+    if isinstance(m, nn.ReLU):
+        return ops.ACT_RELU
     raise NotImplementedError(f"activation {m.__class__.__name__} has no HIP kernel")
 
 
@@ -337,6 +346,42 @@ class Dropout(nn.Dropout):
 
     def forward(self, x: Tensor) -> Tensor:
         return ops.dropout(x, self.p, self.training)
+
+
+class Dropout2d(nn.Dropout2d):
+    """cvnets/layers/dropout.py:32-50"""
+
+    def __init__(self, p: float = 0.5, inplace: bool = False):
+        super().__init__(p=p, inplace=inplace)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return ops.dropout2d(x, self.p, self.training)
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
+    """cvnets/layers/pooling.py (AdaptiveAvgPool2d); output_size 1 only (the ASPP image-pooling branch)"""
+
+    def forward(self, x: Tensor) -> Tensor:
+        size = self.output_size if isinstance(self.output_size, int) else (self.output_size[0] if self.output_size[0] == self.output_size[1] else None)
+        if size != 1:
+            raise NotImplementedError("adaptive average pooling to bins other than 1x1 is not on the HIP path (PSPNet)")
+        y = ops.GlobalAvgPool.apply(ops.to_nhwc(x))
+        return ops.fmap_of(y, y.shape[0], 1, 1)
+
+
+class UpSample(nn.Upsample):
+    """cvnets/layers/upsample.py (nn.Upsample); bilinear only, both corner conventions"""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.mode != "bilinear":
+            raise NotImplementedError("only bilinear up-sampling is on the HIP path")
+        H, W = x.shape[-2:]
+        if self.size is not None:
+            Ho, Wo = (self.size, self.size) if isinstance(self.size, int) else tuple(self.size)
+        else:
+            sf = self.scale_factor if isinstance(self.scale_factor, (tuple, list)) else (self.scale_factor, self.scale_factor)
+            Ho, Wo = int(H * sf[0]), int(W * sf[1])
+        return ops.resize_bilinear(ops.to_nhwc(x), Ho, Wo, bool(self.align_corners))
 
 
 class StochasticDepth(nn.Module):

@@ -13,6 +13,7 @@ Tensor conventions
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import itertools
@@ -23,7 +24,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 _COMPUTE_DTYPE: Optional[torch.dtype] = None
 
 
@@ -1361,6 +1362,72 @@ def dropout(x, p: float, training: bool):
     if not training or p <= 0.0:
         return x
     return DropoutFn.apply(x, float(p), next_stream_id())
+
+
+class Dropout2dFn(torch.autograd.Function):
+    """nn.Dropout2d on an NHWC map (cvnets/layers/dropout.py:32-50): whole channels of a sample are zeroed, the rest scaled by 1/(1-p);
+    the keep mask is a function of (seed, stream id, sample, channel) and is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, stream_id):
+        _check_dev(x)
+        B, C, H, W = x.shape
+        y = nhwc_empty(B, C, H, W, x.dtype, x.device)
+        seed = dropout_seed(x.device)
+        _lib.call("cvh_dropout2d", _dt(x), _p(x), _p(y), B, H * W, C, float(p), _p(seed), stream_id, _stream())
+        ctx.seed = seed
+        ctx.cfg = (float(p), stream_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, stream_id = ctx.cfg
+        dy = as_nhwc(dy)
+        B, C, H, W = dy.shape
+        dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
+        _lib.call("cvh_dropout2d", _dt(dy), _p(dy), _p(dx), B, H * W, C, p, _p(ctx.seed), stream_id, _stream())
+        return dx, None, None
+
+
+def dropout2d(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    return Dropout2dFn.apply(to_nhwc(x), float(p), next_stream_id())
+
+
+class CatChannelsFn(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) of NHWC maps with channel counts that are multiples of 8 (ASPP branches, cvnets/modules/aspp_block.py:118-121);
+    backward splits the gradient back (the same kernel, inverse direction)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        for x in xs:
+            _check_dev(x)
+        B, _, H, W = xs[0].shape
+        cs = [int(x.shape[1]) for x in xs]
+        y = nhwc_empty(B, sum(cs), H, W, xs[0].dtype, xs[0].device)
+        ptrs = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        chans = (ctypes.c_int * len(xs))(*cs)
+        _lib.call("cvh_cat_channels", _dt(y), ptrs, chans, len(xs), _p(y), B * H * W, 0, _stream())
+        ctx.meta = (B, H, W, cs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, cs = ctx.meta
+        dy = as_nhwc(dy)
+        outs = [nhwc_empty(B, c, H, W, dy.dtype, dy.device) for c in cs]
+        ptrs = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        chans = (ctypes.c_int * len(outs))(*cs)
+        _lib.call("cvh_cat_channels", _dt(dy), ptrs, chans, len(outs), _p(dy), B * H * W, 1, _stream())
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    xs = [to_nhwc(x) for x in xs]
+    if len(xs) > 8 or any(x.shape[1] % 8 for x in xs):
+        raise NotImplementedError("channel concat of more than 8 tensors / channel counts that are not multiples of 8")
+    return CatChannelsFn.apply(*xs)
 
 
 # ------------------------------------------------------------------------------------------------

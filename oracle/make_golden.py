@@ -531,6 +531,78 @@ def run_endpoints_case(outdir, name="mobilevit_s_os8_96_b2", mode="small", outpu
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
     print(name, {k: tuple(v.shape) for k, v in ep.items()}, "loss", float(loss))
 
+def build_reference_segmentation():
+    """cvnets.get_model(opts) on config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml (sync_batch_norm -> batch_norm, dropouts 0)"""
+    os.chdir(REF)
+    import cvnets
+    from options.utils import flatten_yaml_as_dict
+    parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+    opts = parser.parse_args([])
+    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml")))
+    for k, v in cfg.items():
+        if hasattr(opts, k):
+            setattr(opts, k, v)
+    setattr(opts, "dataset.category", "segmentation")
+    setattr(opts, "dev.device", "cpu")
+    setattr(opts, "model.classification.pretrained", None)
+    setattr(opts, "model.normalization.name", "batch_norm")
+    for k in ("model.classification.mit.dropout", "model.classification.mit.attn_dropout", "model.classification.mit.ffn_dropout",
+              "model.classification.classifier_dropout", "model.segmentation.classifier_dropout", "model.segmentation.deeplabv3.aspp_dropout",
+              "model.segmentation.aux_dropout"):
+        setattr(opts, k, 0.0)
+    import logging
+    logging.disable(logging.CRITICAL)
+    return cvnets.get_model(opts)
+
+
+def run_segmentation_case(outdir, name="deeplabv3_mobilevit_s_96_b2", batch=2, res=96):
+    """DeepLabv3 head on the MobileViT-S encoder, built by the reference's own builder from
+    config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml (output stride 8, ASPP 512 channels, rates 12/24/36, ReLU head, auxiliary
+    head; sync_batch_norm -> batch_norm for the single-process CPU run, dropouts 0).  The head restatement oracle/seg_oracle.py must
+    reproduce the reference bit for bit on the reference's own end points before the reference's outputs are written."""
+    torch.manual_seed(0)
+    from oracle import seg_oracle
+    model = build_reference_segmentation()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)
+    x = seeded_input((batch, 3, res, res), seed=1)
+    g = torch.Generator().manual_seed(5)
+    target = torch.randint(0, 21, (batch, res, res), generator=g)
+    target[:, :4, :] = 255  # ignored border, as the VOC masks have
+    model.eval()
+    with torch.no_grad():
+        mask_eval = model(x)
+    model.train()
+    ep = model.encoder.extract_end_points_all(x, use_l5=True, use_l5_exp=False)
+    # pin the head restatement on the reference's own end points (fresh state: running statistics as loaded)
+    o_mask, o_aux, o_bn = seg_oracle.deeplabv3_head(sd, "seg_head", {k: v.detach() for k, v in ep.items() if v is not None}, rates=(12, 24, 36), output_stride=8)
+    model.load_state_dict(sd, strict=True)
+    mask, aux = model(x)
+    loss = seg_oracle.seg_loss(mask, aux, target)
+    assert float((o_mask - mask).abs().max()) == 0.0 and float((o_aux - aux).abs().max()) == 0.0, "head restatement differs from the reference"
+    for k, v in o_bn.items():
+        assert float((v - model.state_dict()[k]).abs().max()) == 0.0, k
+    model.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    names = list(grads.keys())
+    out = {"mask_eval": mask_eval.numpy(), "mask_train": mask.detach().numpy(), "aux_train": aux.detach().numpy(), "loss": np.float32(loss.item()),
+           "target": target.numpy().astype(np.int16), "grad_names": np.array(names),
+           "grad_norm": np.array([grads[k].norm().item() for k in names], dtype=np.float64)}
+    for k in names:
+        if k.startswith("seg_head") and grads[k].numel() <= 600000:
+            out["grad::" + k] = grads[k].numpy()
+    for k in ("encoder.conv_1.block.conv.weight", "encoder.layer_5.1.fusion.block.conv.weight", "encoder.layer_4.0.block.conv_3x3.block.conv.weight"):
+        out["grad::" + k] = grads[k].numpy()
+    for k, v in model.state_dict().items():
+        if k.startswith("seg_head") and ("running_mean" in k or "running_var" in k):
+            out["bn::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    json.dump({k: list(v) for k, v in shapes.items()}, open(os.path.join(outdir, "deeplabv3_mobilevit_s_keys.json"), "w"))
+    print(name, tuple(mask.shape), tuple(aux.shape), "loss", float(loss), "head restatement == reference")
+
+
 LARGE_CASES = [("mobilevit_s_256_b16", "small", 16, 256)]        # the BASELINE configuration at a batch where train-mode BatchNorm noise is small
 LARGE_VIT_CASES = [("vit_tiny_224_b16", "tiny", 16, 224)]
 LARGE_V2_CASES = [("mobilevitv2_w100_256_b16", 1.0, 16, 256)]
@@ -539,6 +611,9 @@ if __name__ == "__main__":
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     torch.set_num_threads(8)
+    if "--segmentation" in sys.argv:
+        run_segmentation_case(outdir)
+        sys.exit(0)
     if "--endpoints" in sys.argv:
         run_endpoints_case(outdir)
         run_endpoints_case(outdir, name="mobilevit_xxs_os16_64_b2", mode="xx_small", output_stride=16, batch=2, res=64)

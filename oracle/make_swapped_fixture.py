@@ -7,7 +7,7 @@ with only cvnets_amd importable and runs it through the HIP kernels (tests/test_
 own module tree, attribute values and opts namespace; parameters are the seeded values of oracle/weights.py (the same the golden
 .npz fixtures were generated with), stored as zeros here and re-seeded after loading to keep the file small.
 
-    python oracle/make_swapped_fixture.py            # writes tests/golden/swapped_mobilevit_{xxs,s}.pt
+    python oracle/make_swapped_fixture.py            # writes tests/golden/swapped_mobilevit_{xxs,s}.pt and swapped_deeplabv3_s.pt
 """
 import os
 import pickle
@@ -35,8 +35,9 @@ def foreign_classes(obj, seen=None, path="model"):
 def main():
     from cvnets_amd import dropin
     cwd = os.getcwd()
-    for tag, mode in (("xxs", "xx_small"), ("s", "small")):
-        model = build_reference_model(mode)
+    from oracle.make_golden import build_reference_segmentation
+    for tag, mode in (("xxs", "xx_small"), ("s", "small"), ("deeplabv3_s", None)):
+        model = build_reference_model(mode) if mode else build_reference_segmentation()
         os.chdir(cwd)
         counts, left = dropin.swap_to_hip(model, strict=True)
         bad = foreign_classes(model)
@@ -46,7 +47,7 @@ def main():
         for b in model.buffers():
             b.data = torch.zeros(0, dtype=b.dtype)
         shapes = {}
-        path = os.path.join(REPO, "tests", "golden", f"swapped_mobilevit_{tag}.pt")
+        path = os.path.join(REPO, "tests", "golden", f"swapped_mobilevit_{tag}.pt" if mode else f"swapped_{tag}.pt")
         blob = pickle.dumps(model)
         assert b"cvnets." not in blob.replace(b"cvnets_amd.", b""), "a reference class leaked into the pickle"
         open(path, "wb").write(blob)

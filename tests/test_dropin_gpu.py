@@ -221,3 +221,46 @@ def test_captured_training_trajectory_matches_oracle(dtype):
     finally:
         ops.set_inplace_param_grads(False)
         cvnets_amd.set_compute_dtype(None)
+
+
+def test_reference_built_segmentation_model_runs_hip_kernels():
+    """The same boundary for the DeepLabv3-on-MobileViT model of config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml: built by the
+    reference's builder, class-swapped (SegEncoderDecoder, DeeplabV3, ASPP, ASPPConv2d, ASPPPooling, UpSample, Dropout2d, ReLU ...),
+    pickled, unpickled here without the reference, and checked against the reference's own outputs (tests/test_segmentation_gpu.py
+    checks the model built by cvnets_amd's constructors against the same fixture)."""
+    import cvnets_amd
+    from oracle.seg_oracle import seg_loss
+    from oracle.weights import seeded_input, seeded_tensor
+
+    gold = np.load(os.path.join(GOLD, "deeplabv3_mobilevit_s_96_b2.npz"))
+    shapes = json.load(open(os.path.join(GOLD, "deeplabv3_mobilevit_s_keys.json")))
+    model = pickle.load(open(os.path.join(GOLD, "swapped_deeplabv3_s.pt"), "rb"))
+    named = dict(model.named_parameters())
+    named.update(dict(model.named_buffers()))
+    assert set(named) == set(shapes)
+    for k, t in named.items():
+        t.data = seeded_tensor(k, tuple(shapes[k]), 0).to(t.dtype)
+    assert {type(m).__module__.split(".")[0] for m in model.modules()} <= {"cvnets_amd", "torch"}
+    model = model.to("cuda:0")
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        x = seeded_input((2, 3, 96, 96), seed=1).cuda()
+        target = torch.from_numpy(gold["target"].astype(np.int64)).cuda()
+        model.eval()
+        with torch.no_grad():
+            assert l2_err(model(x).float().cpu(), torch.from_numpy(gold["mask_eval"])) < 1e-4
+        model.train()
+        model.zero_grad(set_to_none=True)
+        mask, aux = model(x)
+        loss = seg_loss(mask.float(), aux.float(), target)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert l2_err(mask.detach().float().cpu(), torch.from_numpy(gold["mask_train"])) < 1e-4
+        assert l2_err(aux.detach().float().cpu(), torch.from_numpy(gold["aux_train"])) < 1e-4
+        assert abs(float(loss.detach()) - float(gold["loss"])) < 1e-4
+        names = [str(n) for n in gold["grad_names"]]
+        gn = torch.tensor([dict(model.named_parameters())[k].grad.float().norm().item() for k in names], dtype=torch.float64)
+        gref = torch.from_numpy(gold["grad_norm"])
+        assert float(((gn - gref).abs() / (gref + 1e-3 * gref.max())).max()) < 2e-3
+    finally:
+        cvnets_amd.set_compute_dtype(None)

@@ -22,7 +22,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK, MFMA_PEAK = 8.0e12, 2.5e15
 # (fwd+bwd GFLOP/img, ideal fwd+bwd MB/img, binding roof)
 ALGO = {"vit_base": (106.25, 190.9, "mfma"), "vit_tiny": (None, None, "mfma"), "mobilevitv2": (24.46, 362.6, "hbm"), "clip": (124.0, None, "mfma"),
-        "mobilevit_s": (12.0, 176.1, "hbm")}
+        "mobilevit_s": (12.0, 176.1, "hbm"), "deeplabv3": (None, None, "hbm")}
 
 
 def build(name, batch, dev):
@@ -51,6 +51,23 @@ def build(name, batch, dev):
         x = torch.randn(batch, 3, 224, 224, device=dev)
         tok = seeded_caption_tokens(batch, 77, 49408, seed=0).to(dev)
         return m, lambda: loss_fn(None, m({"image": x, "text": tok}))["total_loss"], "ViT-B/16 224x224 + 12x512 text, ctx 77"
+    if name == "deeplabv3":
+        # config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml: MobileViT-S encoder at output stride 8, ASPP 512 channels, rates 12/24/36,
+        # auxiliary head, 512 x 512 crops; loss of loss_fn/segmentation/cross_entropy.py (torch: adjacent to the path)
+        import torch.nn.functional as F
+        from cvnets_amd.layers import default_opts
+        opts = default_opts(**{"model.classification.mit.mode": "small", "model.segmentation.output_stride": 8, "model.segmentation.n_classes": 21,
+                               "model.segmentation.use_aux_head": True, "model.segmentation.use_level5_exp": False,
+                               "model.segmentation.deeplabv3.aspp_out_channels": 512, "model.segmentation.deeplabv3.aspp_rates": (12, 24, 36)})
+        m = cvnets_amd.build_deeplabv3_mobilevit(opts).to(dev).train()
+        x = torch.randn(batch, 3, 512, 512, device=dev)
+        y = torch.randint(0, 21, (batch, 512, 512), device=dev)
+
+        def seg_loss():
+            mask, aux = m(x)
+            aux = F.interpolate(aux.float(), size=y.shape[-2:], mode="bilinear", align_corners=True)
+            return F.cross_entropy(mask.float(), y, ignore_index=255) + 0.4 * F.cross_entropy(aux, y, ignore_index=255)
+        return m, seg_loss, "DeepLabv3 + MobileViT-S, 512x512, output stride 8"
     raise SystemExit(f"unknown model {name}")
 
 
@@ -195,7 +212,7 @@ def run_vbs(steps, warmup, dtype):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--models", default="vit_base,mobilevitv2,clip")
-    ap.add_argument("--batch", default="vit_base=128,vit_tiny=256,mobilevitv2=128,clip=128,mobilevit_s=128")
+    ap.add_argument("--batch", default="vit_base=128,vit_tiny=256,mobilevitv2=128,clip=128,mobilevit_s=128,deeplabv3=32")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")

@@ -27,7 +27,15 @@ ALGO = {"vit_base": (106.25, 190.9, "mfma"), "vit_tiny": (None, None, "mfma"), "
 
 def build(name, batch, dev):
     import cvnets_amd
-    from oracle.weights import seeded_caption_tokens
+
+    def seeded_caption_tokens(batch: int, ctx: int, vocab: int, seed: int) -> torch.Tensor:
+        """synthetic captions: ids in [1, vocab-2], one EOT (= vocab-1) at a random position >= 4, padding (0) after it"""
+        g = torch.Generator().manual_seed(seed)
+        tok = torch.randint(1, vocab - 1, (batch, ctx), generator=g)
+        eot = torch.randint(4, ctx, (batch,), generator=g)
+        pos = torch.arange(ctx)[None, :]
+        tok = torch.where(pos == eot[:, None], torch.full_like(tok, vocab - 1), tok)
+        return torch.where(pos > eot[:, None], torch.zeros_like(tok), tok)
 
     if name in ("vit_base", "vit_tiny"):
         m = cvnets_amd.build_vit(name.split("_")[1], **{"model.classification.vit.dropout": 0.2 if name == "vit_base" else 0.0}).to(dev).train()

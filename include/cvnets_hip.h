@@ -200,6 +200,10 @@ int cvh_sum_partials(const float* part, int R, int stride, int Wd, float* out, f
 /* GlobalPool(mean) cvnets/layers/global_pool.py:60-71 */
 int cvh_pool_fwd(int dtype, const void* x, void* y, int B, int HW, int C, void* stream);
 int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, int C, void* stream);
+/* nn.AdaptiveAvgPool2d(OS) on x[B][H][W][C] -> y[B][OS][OS][C] with torch's (overlapping) windows; PSPNet pyramid bins
+ * (cvnets/modules/pspnet_module.py:73-88), OS = 1 = global pool.  bwd = exact adjoint. */
+int cvh_adaptive_pool_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int OS, void* stream);
+int cvh_adaptive_pool_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int OS, void* stream);
 /* Dropout cvnets/layers/dropout.py:11-29: counter-based mask = f(*seed, stream_id, element index) */
 int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned int stream_id,
                 void* stream);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "cvh_sum_partials": [P, I, I, I, P, F, I, P],
     "cvh_pool_fwd": [I, P, P, I, I, I, P],
     "cvh_pool_bwd": [I, P, P, I, I, I, P],
+    "cvh_adaptive_pool_fwd": [I, P, P, I, I, I, I, I, P],
+    "cvh_adaptive_pool_bwd": [I, P, P, I, I, I, I, I, P],
     "cvh_dropout": [I, P, P, L, F, P, U, P],
     "cvh_seed_advance": [P, P],
     "cvh_drop_path": [I, P, P, P, L, I, I, I, I, I, F, P, U, P],

@@ -53,6 +53,8 @@ _BY_NAME = {
     "ASPP": segmentation.ASPP,
     "ASPPConv2d": segmentation.ASPPConv2d,
     "ASPPPooling": segmentation.ASPPPooling,
+    "PSPNet": segmentation.PSPNet,
+    "PSP": segmentation.PSP,
     "Dropout2d": layers.Dropout2d,
     "AdaptiveAvgPool2d": layers.AdaptiveAvgPool2d,
     "UpSample": layers.UpSample,

@@ -359,14 +359,13 @@ class Dropout2d(nn.Dropout2d):
 
 
 class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):
-    """cvnets/layers/pooling.py (AdaptiveAvgPool2d); output_size 1 only (the ASPP image-pooling branch)"""
+    """cvnets/layers/pooling.py (AdaptiveAvgPool2d): the ASPP image-pooling branch (1) and the PSPNet pyramid bins (1, 2, 3, 6)"""
 
     def forward(self, x: Tensor) -> Tensor:
         size = self.output_size if isinstance(self.output_size, int) else (self.output_size[0] if self.output_size[0] == self.output_size[1] else None)
-        if size != 1:
-            raise NotImplementedError("adaptive average pooling to bins other than 1x1 is not on the HIP path (PSPNet)")
-        y = ops.GlobalAvgPool.apply(ops.to_nhwc(x))
-        return ops.fmap_of(y, y.shape[0], 1, 1)
+        if size is None:
+            raise NotImplementedError("non-square adaptive pooling is not on the HIP path")
+        return ops.adaptive_avg_pool(x, size)
 
 
 class UpSample(nn.Upsample):

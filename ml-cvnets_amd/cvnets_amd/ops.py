@@ -1092,6 +1092,31 @@ class GlobalAvgPool(torch.autograd.Function):
         return dx
 
 
+class AdaptiveAvgPool(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(OS) on an NHWC map -> [B, C, OS, OS] (cvnets/modules/pspnet_module.py:73-88; OS = 1: ASPP image pooling)"""
+
+    @staticmethod
+    def forward(ctx, x, OS):
+        _check_dev(x)
+        B, C, H, W = x.shape
+        y = nhwc_empty(B, C, OS, OS, x.dtype, x.device)
+        _lib.call("cvh_adaptive_pool_fwd", _dt(x), _p(x), _p(y), B, H, W, C, OS, _stream())
+        ctx.shape = (B, C, H, W, OS)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, OS = ctx.shape
+        dy = as_nhwc(dy)
+        dx = nhwc_empty(B, C, H, W, dy.dtype, dy.device)
+        _lib.call("cvh_adaptive_pool_bwd", _dt(dy), _p(dy), _p(dx), B, H, W, C, OS, _stream())
+        return dx, None
+
+
+def adaptive_avg_pool(x, OS: int):
+    return AdaptiveAvgPool.apply(to_nhwc(x), int(OS))
+
+
 class ResizeBilinear(torch.autograd.Function):
     """F.interpolate(x, size, mode="bilinear", align_corners=False) on an NHWC map (mobilevit_block.py:191-200, 260-266)."""
 

@@ -5,12 +5,13 @@ Mirrors (same constructor arguments, attribute tree and state_dict keys, so a re
   cvnets/models/segmentation/heads/base_seg_head.py:24-112   BaseSegHead (aux head, up-sampling of the mask)
   cvnets/models/segmentation/heads/deeplabv3.py:19-126  DeeplabV3
   cvnets/modules/aspp_block.py:22-248                   ASPP, ASPPConv2d, ASPPPooling
+  cvnets/models/segmentation/heads/pspnet.py:19-115     PSPNet;  cvnets/modules/pspnet_module.py:17-114  PSP
 
 Every tensor op runs on the HIP kernels of the backbone path: dilated dense 3x3 / 1x1 convs + BatchNorm + ReLU (cvh_conv_gemm, cvh_bn_*),
 global average pool, bilinear resize (both corner conventions), channel concat (cvh_cat_channels), Dropout2d (cvh_dropout2d).  The
 classifier's 21 classes are not a multiple of the 8-channel NHWC granule: its weight / bias are zero-padded to 24 output channels
 (autograd-visible padding of two tiny tensors), the mask is up-sampled with 24 channels and the first n_classes are returned.
-Not built: the separable-conv ASPP variant, PSPNet (needs adaptive pooling to 2/3/6 bins), SSD detection heads.
+PSPNet: adaptive average pools to 1/2/3/6 bins (cvh_adaptive_pool_*).  Not built: the separable-conv ASPP variant, SSD detection heads.
 """
 from typing import Dict, Optional, Tuple, Union
 
@@ -175,6 +176,61 @@ class DeeplabV3(BaseSegHead):
         return _conv_padded_classes(self.classifier, self.aspp(x))
 
 
+class PSP(nn.Module):
+    """cvnets/modules/pspnet_module.py:17-114: pyramid pooling — adaptive average pools to `pool_sizes` bins, 1x1 conv-BN-act each,
+    bilinear (align_corners=True) back to the input size, concat with the input, 3x3 conv-BN-act fusion, Dropout2d"""
+
+    def __init__(self, opts, in_channels: int, out_channels: int, pool_sizes: Optional[Tuple[int, ...]] = (1, 2, 3, 6),
+                 dropout: Optional[float] = 0.0, *args, **kwargs) -> None:
+        super().__init__()
+        reduction_dim = in_channels // len(pool_sizes)
+        reduction_dim = (reduction_dim // 16) * 16
+        channels_after_concat = (reduction_dim * len(pool_sizes)) + in_channels
+        self.psp_branches = nn.ModuleList([self._make_psp_layer(opts, o_size=ps, in_channels=in_channels, out_channels=reduction_dim)
+                                           for ps in pool_sizes])
+        self.fusion = nn.Sequential(
+            ConvLayer2d(opts=opts, in_channels=channels_after_concat, out_channels=out_channels, kernel_size=3, stride=1, use_norm=True, use_act=True),
+            Dropout2d(p=dropout))
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.pool_sizes = pool_sizes
+        self.inner_channels = reduction_dim
+        self.dropout = dropout
+
+    @staticmethod
+    def _make_psp_layer(opts, o_size: int, in_channels: int, out_channels: int) -> nn.Module:
+        return nn.Sequential(AdaptiveAvgPool2d(output_size=(o_size, o_size)),
+                             ConvLayer2d(opts, in_channels=in_channels, out_channels=out_channels, kernel_size=1, bias=False, use_norm=True, use_act=True))
+
+    def forward(self, x: Tensor, *args, **kwargs) -> Tensor:
+        H, W = x.shape[-2:]
+        x = ops.to_nhwc(x)
+        out = [x] + [ops.resize_bilinear(ops.to_nhwc(branch(x)), H, W, True) for branch in self.psp_branches]
+        return self.fusion(ops.cat_channels(out))
+
+    def __repr__(self):
+        return "{}(in_channels={}, out_channels={}, pool_sizes={}, inner_channels={}, dropout_2d={})".format(
+            self.__class__.__name__, self.in_channels, self.out_channels, self.pool_sizes, self.inner_channels, self.dropout)
+
+
+class PSPNet(BaseSegHead):
+    """cvnets/models/segmentation/heads/pspnet.py:19-115"""
+
+    def __init__(self, opts, enc_conf: Dict, use_l5_exp: Optional[bool] = False, *args, **kwargs) -> None:
+        psp_out_channels = opt(opts, "model.segmentation.pspnet.psp_out_channels", 512)
+        psp_pool_sizes = opt(opts, "model.segmentation.pspnet.psp_pool_sizes", [1, 2, 3, 6])
+        psp_dropout = opt(opts, "model.segmentation.pspnet.psp_dropout", 0.1)
+        super().__init__(opts=opts, enc_conf=enc_conf, use_l5_exp=use_l5_exp)
+        psp_in_channels = self.enc_l5_channels if not self.use_l5_exp else self.enc_l5_exp_channels
+        self.psp_layer = PSP(opts=opts, in_channels=psp_in_channels, out_channels=psp_out_channels, pool_sizes=tuple(psp_pool_sizes), dropout=psp_dropout)
+        self.classifier = ConvLayer2d(opts=opts, in_channels=psp_out_channels, out_channels=self.n_seg_classes, kernel_size=1, stride=1,
+                                      use_norm=False, use_act=False, bias=True)
+
+    def forward_seg_head(self, enc_out: Dict) -> Tensor:
+        x = enc_out["out_l5_exp"] if self.use_l5_exp else enc_out["out_l5"]
+        return _conv_padded_classes(self.classifier, self.psp_layer(x))
+
+
 class SegEncoderDecoder(nn.Module):
     """cvnets/models/segmentation/enc_dec.py:21-153 (forward :91-108)"""
 
@@ -193,15 +249,22 @@ class SegEncoderDecoder(nn.Module):
         return self.seg_head(enc_out=enc_end_points, *args, **kwargs)
 
 
-def build_deeplabv3_mobilevit(opts, head_activation: str = "relu") -> SegEncoderDecoder:
-    """config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml: MobileViT encoder (its own activation, dilated to
-    model.segmentation.output_stride) + DeepLabv3 head whose ConvLayer2d blocks use model.activation.name (relu in the reference YAMLs)."""
+def build_segmentation(opts, encoder: str = "mobilevit", head: str = "deeplabv3", head_activation: str = "relu") -> SegEncoderDecoder:
+    """config/segmentation/{pascal_voc,ade20k}/{deeplabv3,pspnet}_mobilevit{,v2}.yaml: a MobileViT / MobileViTv2 encoder (its own
+    activation, layers 4-5 dilated to model.segmentation.output_stride) + a DeepLabv3 / PSPNet head whose ConvLayer2d blocks use
+    model.segmentation.activation.name (relu in the reference YAMLs)."""
     import copy
 
-    from .models import MobileViT
+    from .models import MobileViT, MobileViTv2
 
-    encoder = MobileViT(opts, output_stride=opt(opts, "model.segmentation.output_stride", None))
+    enc_cls = {"mobilevit": MobileViT, "mobilevit_v2": MobileViTv2}[encoder]
+    enc = enc_cls(opts, output_stride=opt(opts, "model.segmentation.output_stride", None))
     head_opts = copy.copy(opts)
     setattr(head_opts, "model.activation.name", head_activation)
-    head = DeeplabV3(head_opts, enc_conf=encoder.model_conf_dict, use_l5_exp=opt(opts, "model.segmentation.use_level5_exp", False))
-    return SegEncoderDecoder(opts, encoder=encoder, seg_head=head)
+    head_cls = {"deeplabv3": DeeplabV3, "pspnet": PSPNet}[head]
+    seg_head = head_cls(head_opts, enc_conf=enc.model_conf_dict, use_l5_exp=opt(opts, "model.segmentation.use_level5_exp", False))
+    return SegEncoderDecoder(opts, encoder=enc, seg_head=seg_head)
+
+
+def build_deeplabv3_mobilevit(opts, head_activation: str = "relu") -> SegEncoderDecoder:
+    return build_segmentation(opts, "mobilevit", "deeplabv3", head_activation)

@@ -531,21 +531,24 @@ def run_endpoints_case(outdir, name="mobilevit_s_os8_96_b2", mode="small", outpu
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
     print(name, {k: tuple(v.shape) for k, v in ep.items()}, "loss", float(loss))
 
-def build_reference_segmentation():
-    """cvnets.get_model(opts) on config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml (sync_batch_norm -> batch_norm, dropouts 0)"""
+def build_reference_segmentation(cfg="deeplabv3_mobilevit", width=None):
+    """cvnets.get_model(opts) on config/segmentation/pascal_voc/<cfg>.yaml (sync_batch_norm -> batch_norm, dropouts 0)"""
     os.chdir(REF)
     import cvnets
     from options.utils import flatten_yaml_as_dict
     parser = cvnets.modeling_arguments(argparse.ArgumentParser())
     opts = parser.parse_args([])
-    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml")))
-    for k, v in cfg.items():
+    cfgd = flatten_yaml_as_dict(yaml.safe_load(open(f"config/segmentation/pascal_voc/{cfg}.yaml")))
+    for k, v in cfgd.items():
         if hasattr(opts, k):
             setattr(opts, k, v)
     setattr(opts, "dataset.category", "segmentation")
     setattr(opts, "dev.device", "cpu")
     setattr(opts, "model.classification.pretrained", None)
     setattr(opts, "model.normalization.name", "batch_norm")
+    if width is not None:
+        setattr(opts, "model.classification.mitv2.width_multiplier", width)
+    setattr(opts, "model.segmentation.pspnet.psp_dropout", 0.0)
     for k in ("model.classification.mit.dropout", "model.classification.mit.attn_dropout", "model.classification.mit.ffn_dropout",
               "model.classification.classifier_dropout", "model.segmentation.classifier_dropout", "model.segmentation.deeplabv3.aspp_dropout",
               "model.segmentation.aux_dropout"):
@@ -555,14 +558,15 @@ def build_reference_segmentation():
     return cvnets.get_model(opts)
 
 
-def run_segmentation_case(outdir, name="deeplabv3_mobilevit_s_96_b2", batch=2, res=96):
+def run_segmentation_case(outdir, name="deeplabv3_mobilevit_s_96_b2", batch=2, res=96, cfg="deeplabv3_mobilevit", width=None, head="deeplabv3",
+                          rates=(12, 24, 36), output_stride=8, keys_name="deeplabv3_mobilevit_s_keys.json"):
     """DeepLabv3 head on the MobileViT-S encoder, built by the reference's own builder from
     config/segmentation/pascal_voc/deeplabv3_mobilevit.yaml (output stride 8, ASPP 512 channels, rates 12/24/36, ReLU head, auxiliary
     head; sync_batch_norm -> batch_norm for the single-process CPU run, dropouts 0).  The head restatement oracle/seg_oracle.py must
     reproduce the reference bit for bit on the reference's own end points before the reference's outputs are written."""
     torch.manual_seed(0)
     from oracle import seg_oracle
-    model = build_reference_segmentation()
+    model = build_reference_segmentation(cfg, width)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = seeded_state_dict(shapes, seed=0)
     model.load_state_dict(sd, strict=True)
@@ -576,7 +580,11 @@ def run_segmentation_case(outdir, name="deeplabv3_mobilevit_s_96_b2", batch=2, r
     model.train()
     ep = model.encoder.extract_end_points_all(x, use_l5=True, use_l5_exp=False)
     # pin the head restatement on the reference's own end points (fresh state: running statistics as loaded)
-    o_mask, o_aux, o_bn = seg_oracle.deeplabv3_head(sd, "seg_head", {k: v.detach() for k, v in ep.items() if v is not None}, rates=(12, 24, 36), output_stride=8)
+    ep_d = {k: v.detach() for k, v in ep.items() if v is not None}
+    if head == "deeplabv3":
+        o_mask, o_aux, o_bn = seg_oracle.deeplabv3_head(sd, "seg_head", ep_d, rates=rates, output_stride=output_stride)
+    else:
+        o_mask, o_aux, o_bn = seg_oracle.pspnet_head(sd, "seg_head", ep_d, pool_sizes=(1, 2, 3, 6), output_stride=output_stride)
     model.load_state_dict(sd, strict=True)
     mask, aux = model(x)
     loss = seg_oracle.seg_loss(mask, aux, target)
@@ -591,15 +599,16 @@ def run_segmentation_case(outdir, name="deeplabv3_mobilevit_s_96_b2", batch=2, r
            "target": target.numpy().astype(np.int16), "grad_names": np.array(names),
            "grad_norm": np.array([grads[k].norm().item() for k in names], dtype=np.float64)}
     for k in names:
-        if k.startswith("seg_head") and grads[k].numel() <= 600000:
+        if k.startswith("seg_head") and grads[k].numel() <= 150000:
             out["grad::" + k] = grads[k].numpy()
-    for k in ("encoder.conv_1.block.conv.weight", "encoder.layer_5.1.fusion.block.conv.weight", "encoder.layer_4.0.block.conv_3x3.block.conv.weight"):
-        out["grad::" + k] = grads[k].numpy()
+    for k in ("encoder.conv_1.block.conv.weight", "encoder.layer_4.0.block.conv_3x3.block.conv.weight", "encoder.layer_5.1.conv_proj.block.conv.weight"):
+        if k in grads:
+            out["grad::" + k] = grads[k].numpy()
     for k, v in model.state_dict().items():
         if k.startswith("seg_head") and ("running_mean" in k or "running_var" in k):
             out["bn::" + k] = v.numpy()
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
-    json.dump({k: list(v) for k, v in shapes.items()}, open(os.path.join(outdir, "deeplabv3_mobilevit_s_keys.json"), "w"))
+    json.dump({k: list(v) for k, v in shapes.items()}, open(os.path.join(outdir, keys_name), "w"))
     print(name, tuple(mask.shape), tuple(aux.shape), "loss", float(loss), "head restatement == reference")
 
 
@@ -613,6 +622,10 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if "--segmentation" in sys.argv:
         run_segmentation_case(outdir)
+        run_segmentation_case(outdir, name="deeplabv3_mobilevitv2_w050_96_b2", cfg="deeplabv3_mobilevitv2", width=0.5, head="deeplabv3", rates=(6, 12, 18),
+                              output_stride=16, keys_name="deeplabv3_mobilevitv2_w050_keys.json")
+        run_segmentation_case(outdir, name="pspnet_mobilevitv2_w050_96_b2", cfg="pspnet_mobilevitv2", width=0.5, head="pspnet", output_stride=16,
+                              keys_name="pspnet_mobilevitv2_w050_keys.json")
         sys.exit(0)
     if "--endpoints" in sys.argv:
         run_endpoints_case(outdir)

@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure only — never imported by the product): CPU / fp32 functional restatement of the DeepLabv3 segmentation
 head over a state_dict, pinned bit-exact against the reference classes by oracle/make_golden.py --segmentation.
 
-Follows  cvnets/modules/aspp_block.py:22-248 (ASPP.forward :118-123, ASPPPooling.forward :238-243),
+Follows  cvnets/modules/pspnet_module.py:17-114 and cvnets/models/segmentation/heads/pspnet.py:19-115 (PSPNet),
+         cvnets/modules/aspp_block.py:22-248 (ASPP.forward :118-123, ASPPPooling.forward :238-243),
          cvnets/models/segmentation/heads/deeplabv3.py:122-126 (forward_seg_head),
          cvnets/models/segmentation/heads/base_seg_head.py:92-112 (forward: up-sampling, auxiliary head),
          loss_fn/segmentation/cross_entropy.py:96-116 (_compute_loss) and :172-176 (total = seg + aux_weight * aux).
@@ -39,6 +40,30 @@ def deeplabv3_head(sd, prefix: str, enc_out: Dict[str, Tensor], rates=(12, 24, 3
     """returns (mask logits [B, n_classes, H, W], auxiliary logits or None, updated BatchNorm running statistics)"""
     bn_state: Dict[str, Tensor] = {}
     y = aspp(sd, prefix + ".aspp.aspp_layer", enc_out["out_l5"], tuple(rates), training, bn_state)
+    y = F.conv2d(y, sd[prefix + ".classifier.block.conv.weight"], sd[prefix + ".classifier.block.conv.bias"])
+    if output_stride != 1:
+        y = F.interpolate(y, scale_factor=float(output_stride), mode="bilinear", align_corners=True)
+    aux = None
+    if use_aux and training:
+        a = _conv_bn_relu(sd, prefix + ".aux_head.0", enc_out["out_l4"], training=training, bn_state=bn_state)
+        aux = F.conv2d(a, sd[prefix + ".aux_head.2.block.conv.weight"], sd[prefix + ".aux_head.2.block.conv.bias"])
+    return y, aux, bn_state
+
+
+def psp(sd, prefix: str, x: Tensor, pool_sizes, training: bool, bn_state: Dict) -> Tensor:
+    """cvnets/modules/pspnet_module.py:91-103"""
+    outs = [x]
+    for i, ps in enumerate(pool_sizes):
+        y = F.adaptive_avg_pool2d(x, ps)
+        y = _conv_bn_relu(sd, f"{prefix}.psp_branches.{i}.1", y, training=training, bn_state=bn_state)
+        outs.append(F.interpolate(y, size=x.shape[-2:], mode="bilinear", align_corners=True))
+    return _conv_bn_relu(sd, prefix + ".fusion.0", torch.cat(outs, dim=1), training=training, bn_state=bn_state)  # Dropout2d: p = 0 in parity runs
+
+
+def pspnet_head(sd, prefix: str, enc_out: Dict[str, Tensor], pool_sizes=(1, 2, 3, 6), output_stride: int = 16, training: bool = True, use_aux: bool = True):
+    """cvnets/models/segmentation/heads/pspnet.py:99-115 + base_seg_head.py:92-112"""
+    bn_state: Dict[str, Tensor] = {}
+    y = psp(sd, prefix + ".psp_layer", enc_out["out_l5"], tuple(pool_sizes), training, bn_state)
     y = F.conv2d(y, sd[prefix + ".classifier.block.conv.weight"], sd[prefix + ".classifier.block.conv.bias"])
     if output_stride != 1:
         y = F.interpolate(y, scale_factor=float(output_stride), mode="bilinear", align_corners=True)

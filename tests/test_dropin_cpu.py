@@ -213,20 +213,28 @@ def test_vbs_shape_schedule_matches_reference():
     assert schedule.vbs_sequence(pairs, 25, epoch=3) == expect
 
 
-def test_segmentation_model_mirrors_the_reference_key_set():
-    """cvnets_amd.build_deeplabv3_mobilevit constructs the module tree of the reference's SegEncoderDecoder + DeeplabV3 (key set and shapes
-    recorded from the reference builder by oracle/make_golden.py --segmentation); runs without a GPU (construction only)."""
+def test_segmentation_models_mirror_the_reference_key_sets():
+    """cvnets_amd.build_segmentation constructs the module trees of the reference's SegEncoderDecoder + DeeplabV3 / PSPNet on MobileViT /
+    MobileViTv2 encoders (key sets and shapes recorded from the reference builder by oracle/make_golden.py --segmentation); runs without
+    a GPU (construction only)."""
     import json
     import os
 
     import cvnets_amd
     from cvnets_amd.layers import default_opts
 
-    shapes = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "deeplabv3_mobilevit_s_keys.json")))
-    opts = default_opts(**{"model.classification.mit.mode": "small", "model.segmentation.output_stride": 8, "model.segmentation.n_classes": 21,
-                           "model.segmentation.use_aux_head": True, "model.segmentation.use_level5_exp": False,
-                           "model.segmentation.deeplabv3.aspp_out_channels": 512, "model.segmentation.deeplabv3.aspp_rates": (12, 24, 36)})
-    model = cvnets_amd.build_deeplabv3_mobilevit(opts)
-    assert {k: list(v.shape) for k, v in model.state_dict().items()} == shapes
-    assert model.encoder.classifier is None and model.encoder.conv_1x1_exp is None
-    assert type(model.seg_head.aspp.aspp_layer.convs[0].block.act).__name__ == "ReLU" and type(model.encoder.conv_1.block.act).__name__ == "Swish"
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    common = {"model.segmentation.n_classes": 21, "model.segmentation.use_aux_head": True, "model.segmentation.use_level5_exp": False,
+              "model.segmentation.deeplabv3.aspp_out_channels": 512}
+    cases = [("mobilevit", "deeplabv3", {"model.classification.mit.mode": "small", "model.segmentation.output_stride": 8,
+                                         "model.segmentation.deeplabv3.aspp_rates": (12, 24, 36)}, "deeplabv3_mobilevit_s_keys.json"),
+             ("mobilevit_v2", "deeplabv3", {"model.classification.mitv2.width_multiplier": 0.5, "model.segmentation.output_stride": 16,
+                                            "model.segmentation.deeplabv3.aspp_rates": (6, 12, 18)}, "deeplabv3_mobilevitv2_w050_keys.json"),
+             ("mobilevit_v2", "pspnet", {"model.classification.mitv2.width_multiplier": 0.5, "model.segmentation.output_stride": 16},
+              "pspnet_mobilevitv2_w050_keys.json")]
+    for enc, head, over, keys in cases:
+        shapes = json.load(open(os.path.join(gold, keys)))
+        model = cvnets_amd.build_segmentation(default_opts(**{**common, **over}), enc, head)
+        assert {k: list(v.shape) for k, v in model.state_dict().items()} == shapes, (enc, head)
+        assert model.encoder.classifier is None and model.encoder.conv_1x1_exp is None
+    assert type(model.seg_head.psp_layer.fusion[0].block.act).__name__ == "ReLU" and type(model.encoder.conv_1.block.act).__name__ == "Swish"

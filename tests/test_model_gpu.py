@@ -165,7 +165,7 @@ def test_unsupported_variants_fail_loudly():
     from cvnets_amd.layers import default_opts
 
     with pytest.raises(NotImplementedError):
-        cvnets_amd.MobileViT(default_opts(**{"model.activation.name": "relu"}))
+        cvnets_amd.MobileViT(default_opts(**{"model.activation.name": "hard_swish"}))
     with pytest.raises(NotImplementedError):
         cvnets_amd.MobileViT(default_opts(**{"model.normalization.name": "group_norm"}))
     m = cvnets_amd.MultiHeadAttention(64, 4).cuda()

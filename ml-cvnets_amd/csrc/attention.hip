@@ -94,8 +94,32 @@ struct TileStager {
   static constexpr int IT = (NROWS * CH + NT - 1) / NT;
   V4<T> q[VEC == 4 ? IT : 1];
   T e[VEC == 4 ? 1 : IT][VEC == 4 ? 1 : VEC];
+  unsigned okm;  // VEC == 4: validity of q[it] (bit it), applied in store()
 
   __device__ __forceinline__ void load(const T* __restrict__ g, int ld, int col0, const int* rowidx, int nrows, int c, int tid) {
+    if constexpr (VEC == 4) {
+      // two branch-free phases: all row indices (LDS) first, then all global loads from clamped addresses; validity is applied when the
+      // registers are written to LDS.  (One `if (ok) { index read; load }` per element serialised an LDS round trip in front of every load
+      // and put the loads behind exec-mask branches — s_waitcnt vmcnt(0) everywhere.)
+      int ri[IT];
+      okm = 0;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NT;
+        const int r = idx / CH, cc = (idx - r * CH) * VEC;
+        const bool in = idx < NROWS * CH && r < nrows && cc < c;
+        ri[it] = rowidx[in ? r : 0];
+        if (in && ri[it] >= 0) okm |= 1u << it;
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NT;
+        const int r = idx / CH, cc = (idx - r * CH) * VEC;
+        const bool ok = (okm >> it) & 1u;
+        q[it] = v4_load<T>(g + (ok ? (size_t)ri[it] * ld + col0 + cc : (size_t)0));
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int idx = tid + it * NT;
@@ -120,6 +144,10 @@ struct TileStager {
       const int r = idx / CH, cc = (idx - r * CH) * VEC;
       if constexpr (VEC == 4) {
         V4<T> v = q[it];
+        if (!((okm >> it) & 1u)) {
+          float z[4] = {0.f, 0.f, 0.f, 0.f};
+          v4_pack(z, v);
+        }
         if (scale != 1.0f) {
           float f[4];
           v4_unpack(v, f);

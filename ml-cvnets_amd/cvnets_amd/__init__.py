@@ -12,6 +12,7 @@ from .clip import CLIP, SimpleImageProjectionHead, TextTransformer, build_clip  
 from .losses import ContrastiveLossClip, CrossEntropy  # noqa: F401
 from .modules import InvertedResidual, LinearAttnFFN, MobileViTBlock, MobileViTBlockv2, TransformerEncoder  # noqa: F401
 from .ops import compute_dtype, set_compute_dtype  # noqa: F401
+from .detection import SeparableConv2d, SingleShotMaskDetector, SSDAnchorGenerator, SSDHead, build_ssd  # noqa: F401
 from .segmentation import ASPP, PSP, DeeplabV3, PSPNet, SegEncoderDecoder, build_deeplabv3_mobilevit, build_segmentation  # noqa: F401
 
 __version__ = "0.1.0"

@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 from torch import nn
 
-from . import clip, layers, models, modules, segmentation
+from . import clip, detection, layers, models, modules, segmentation
 
 # reference class name -> cvnets_amd class (matched by name AND by defining package to avoid swapping foreign classes)
 _BY_NAME = {
@@ -55,6 +55,10 @@ _BY_NAME = {
     "ASPPPooling": segmentation.ASPPPooling,
     "PSPNet": segmentation.PSPNet,
     "PSP": segmentation.PSP,
+    "SingleShotMaskDetector": detection.SingleShotMaskDetector,
+    "SSDHead": detection.SSDHead,
+    "SeparableConv2d": detection.SeparableConv2d,
+    "SSDAnchorGenerator": detection.SSDAnchorGenerator,
     "Dropout2d": layers.Dropout2d,
     "AdaptiveAvgPool2d": layers.AdaptiveAvgPool2d,
     "UpSample": layers.UpSample,

@@ -612,6 +612,77 @@ def run_segmentation_case(outdir, name="deeplabv3_mobilevit_s_96_b2", batch=2, r
     print(name, tuple(mask.shape), tuple(aux.shape), "loss", float(loss), "head restatement == reference")
 
 
+def build_reference_ssd():
+    """cvnets.get_model(opts) on config/detection/ssd_coco/mobilevit.yaml (sync_batch_norm -> batch_norm, dropouts 0, 81 classes)"""
+    os.chdir(REF)
+    import cvnets
+    from options.utils import flatten_yaml_as_dict
+    parser = cvnets.modeling_arguments(argparse.ArgumentParser())
+    opts = parser.parse_args([])
+    cfg = flatten_yaml_as_dict(yaml.safe_load(open("config/detection/ssd_coco/mobilevit.yaml")))
+    for k, v in cfg.items():
+        if hasattr(opts, k):
+            setattr(opts, k, v)
+    setattr(opts, "dataset.category", "detection")
+    setattr(opts, "dev.device", "cpu")
+    setattr(opts, "model.classification.pretrained", None)
+    setattr(opts, "model.normalization.name", "batch_norm")
+    setattr(opts, "model.detection.n_classes", 81)
+    for k in ("model.classification.mit.dropout", "model.classification.mit.attn_dropout", "model.classification.mit.ffn_dropout",
+              "model.classification.classifier_dropout"):
+        setattr(opts, k, 0.0)
+    import logging
+    logging.disable(logging.CRITICAL)
+    return cvnets.get_model(opts)
+
+
+def run_detection_case(outdir, name="ssd_mobilevit_s_160_b2", batch=2, res=160):
+    """the SSD head on the MobileViT-S encoder built by the reference's own builder (training forward: scores, boxes).
+    oracle/det_oracle.py must reproduce the reference bit for bit on the reference's own end points before the outputs are written."""
+    torch.manual_seed(0)
+    from oracle import det_oracle
+    model = build_reference_ssd()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)
+    x = seeded_input((batch, 3, res, res), seed=1)
+    model.eval()
+    with torch.no_grad():
+        ev = model.ssd_forward(model.get_backbone_features(x), device="cpu")
+    model.train()
+    ep = model.encoder.extract_end_points_all(x)
+    o_scores, o_boxes, o_bn = det_oracle.ssd_forward(sd, {k: v.detach() for k, v in ep.items() if v is not None}, list(model.output_strides), 81)
+    model.load_state_dict(sd, strict=True)
+    out = model(x)
+    scores, boxes = out["scores"], out["boxes"]
+    assert float((o_scores - scores).abs().max()) == 0.0 and float((o_boxes - boxes).abs().max()) == 0.0, "SSD restatement differs from the reference"
+    for k, v in o_bn.items():
+        assert float((v - model.state_dict()[k]).abs().max()) == 0.0, k
+    g = torch.Generator().manual_seed(9)
+    t_s, t_b = torch.randn(scores.shape, generator=g), torch.randn(boxes.shape, generator=g)
+    loss = torch.nn.functional.mse_loss(scores, t_s) + torch.nn.functional.mse_loss(boxes, t_b)
+    model.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    names = list(grads.keys())
+    anchors = ev[2]
+    res_ = {"scores_eval": ev[0].numpy().astype(np.float16), "boxes_eval": ev[1].numpy(), "scores_train": scores.detach().numpy().astype(np.float32),
+            "boxes_train": boxes.detach().numpy(), "anchors": anchors.numpy(), "loss": np.float32(loss.item()), "grad_names": np.array(names),
+            "grad_norm": np.array([grads[k].norm().item() for k in names], dtype=np.float64),
+            "output_strides": np.array(list(model.output_strides))}
+    for k in names:
+        if not k.startswith("encoder") and grads[k].numel() <= 70000:
+            res_["grad::" + k] = grads[k].numpy()
+    for k in ("encoder.conv_1.block.conv.weight", "encoder.layer_5.1.conv_proj.block.conv.weight"):
+        res_["grad::" + k] = grads[k].numpy()
+    for k, v in model.state_dict().items():
+        if not k.startswith("encoder") and ("running_mean" in k or "running_var" in k):
+            res_["bn::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **res_)
+    json.dump({k: list(v) for k, v in shapes.items()}, open(os.path.join(outdir, "ssd_mobilevit_s_keys.json"), "w"))
+    print(name, tuple(scores.shape), tuple(boxes.shape), tuple(anchors.shape), "loss", float(loss), "SSD restatement == reference")
+
+
 LARGE_CASES = [("mobilevit_s_256_b16", "small", 16, 256)]        # the BASELINE configuration at a batch where train-mode BatchNorm noise is small
 LARGE_VIT_CASES = [("vit_tiny_224_b16", "tiny", 16, 224)]
 LARGE_V2_CASES = [("mobilevitv2_w100_256_b16", 1.0, 16, 256)]
@@ -620,6 +691,9 @@ if __name__ == "__main__":
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     torch.set_num_threads(8)
+    if "--detection" in sys.argv:
+        run_detection_case(outdir)
+        sys.exit(0)
     if "--segmentation" in sys.argv:
         run_segmentation_case(outdir)
         run_segmentation_case(outdir, name="deeplabv3_mobilevitv2_w050_96_b2", cfg="deeplabv3_mobilevitv2", width=0.5, head="deeplabv3", rates=(6, 12, 18),

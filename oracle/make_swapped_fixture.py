@@ -7,7 +7,7 @@ with only cvnets_amd importable and runs it through the HIP kernels (tests/test_
 own module tree, attribute values and opts namespace; parameters are the seeded values of oracle/weights.py (the same the golden
 .npz fixtures were generated with), stored as zeros here and re-seeded after loading to keep the file small.
 
-    python oracle/make_swapped_fixture.py            # writes tests/golden/swapped_mobilevit_{xxs,s}.pt and swapped_deeplabv3_s.pt
+    python oracle/make_swapped_fixture.py            # writes tests/golden/swapped_mobilevit_{xxs,s}.pt, swapped_deeplabv3_s.pt, swapped_ssd_s.pt
 """
 import os
 import pickle
@@ -35,9 +35,12 @@ def foreign_classes(obj, seen=None, path="model"):
 def main():
     from cvnets_amd import dropin
     cwd = os.getcwd()
-    from oracle.make_golden import build_reference_segmentation
-    for tag, mode in (("xxs", "xx_small"), ("s", "small"), ("deeplabv3_s", None)):
-        model = build_reference_model(mode) if mode else build_reference_segmentation()
+    from oracle.make_golden import build_reference_segmentation, build_reference_ssd
+    for tag, mode in (("xxs", "xx_small"), ("s", "small"), ("deeplabv3_s", None), ("ssd_s", None)):
+        model = build_reference_model(mode) if mode else (build_reference_ssd() if tag == "ssd_s" else build_reference_segmentation())
+        if tag == "ssd_s":
+            model.match_prior = None  # host-side box matcher (loss / eval post-processing): not a module, stays on the reference side
+            model.opts = None
         os.chdir(cwd)
         counts, left = dropin.swap_to_hip(model, strict=True)
         bad = foreign_classes(model)

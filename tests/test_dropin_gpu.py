@@ -264,3 +264,36 @@ def test_reference_built_segmentation_model_runs_hip_kernels():
         assert float(((gn - gref).abs() / (gref + 1e-3 * gref.max())).max()) < 2e-3
     finally:
         cvnets_amd.set_compute_dtype(None)
+
+
+def test_reference_built_ssd_model_runs_hip_kernels():
+    """The boundary for the SSD detector of config/detection/ssd_coco/mobilevit.yaml: built by the reference's builder, class-swapped
+    (SingleShotMaskDetector, SSDHead, SeparableConv2d, SSDAnchorGenerator ...), pickled without its host-side matcher, unpickled here
+    without the reference, and checked against the reference's own training outputs."""
+    import cvnets_amd
+    from oracle.weights import seeded_input, seeded_tensor
+
+    gold = np.load(os.path.join(GOLD, "ssd_mobilevit_s_160_b2.npz"))
+    shapes = json.load(open(os.path.join(GOLD, "ssd_mobilevit_s_keys.json")))
+    model = pickle.load(open(os.path.join(GOLD, "swapped_ssd_s.pt"), "rb"))
+    named = dict(model.named_parameters())
+    named.update(dict(model.named_buffers()))
+    assert set(named) == set(shapes)
+    for k, t in named.items():
+        t.data = seeded_tensor(k, tuple(shapes[k]), 0).to(t.dtype)
+    assert {type(m).__module__.split(".")[0] for m in model.modules()} <= {"cvnets_amd", "torch"}
+    model = model.to("cuda:0").train()
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        x = seeded_input((2, 3, 160, 160), seed=1).cuda()
+        out = model(x)
+        assert l2_err(out["scores"].detach().float().cpu(), torch.from_numpy(gold["scores_train"])) < 1e-4
+        assert l2_err(out["boxes"].detach().float().cpu(), torch.from_numpy(gold["boxes_train"])) < 1e-4
+        g = torch.Generator().manual_seed(9)
+        t_s, t_b = torch.randn(out["scores"].shape, generator=g).cuda(), torch.randn(out["boxes"].shape, generator=g).cuda()
+        loss = F.mse_loss(out["scores"].float(), t_s) + F.mse_loss(out["boxes"].float(), t_b)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(gold["loss"])) < 1e-4
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    finally:
+        cvnets_amd.set_compute_dtype(None)

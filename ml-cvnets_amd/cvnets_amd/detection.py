@@ -12,7 +12,6 @@ the 8-channel NHWC granule: the pointwise weight / bias are zero-padded (autogra
 padding is dropped when the map is reshaped to [B, anchors, 4 + n_classes].  Not on the HIP path: box decoding + NMS of the eval /
 predict branch (torchvision ops on a few hundred boxes), the matcher / multibox loss (adjacent, kept), the FPN variant.
 """
-from itertools import product
 from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
@@ -147,18 +146,22 @@ class SSDAnchorGenerator(nn.Module):
 
     @torch.no_grad()
     def _generate_anchors(self, height: int, width: int, output_stride: int, device="cpu") -> Tensor:
-        mn, mx = self.sizes[output_stride]["min"], self.sizes[output_stride]["max"]
+        """[H' * W' * A, 4] = (cx, cy, w, h) in image fractions, cell-major then anchor-major: per cell the min-size square, the
+        sqrt(min * next) square, then (w * sqrt(r), h / sqrt(r)) and its transpose for every aspect ratio r.  Built in float64 on the host
+        (as the reference's Python-float loop does) and rounded to float32 once."""
+        mn, mx = float(self.sizes[output_stride]["min"]), float(self.sizes[output_stride]["max"])
         step = max(1, self.sizes[output_stride]["step"])
         start = max(0, step // 2)
-        out = []
-        for y, x in product(range(start, height, step), range(start, width, step)):
-            cx, cy = (x + 0.5) / width, (y + 0.5) / height
-            out.append([cx, cy, mn, mn])
-            out.append([cx, cy, mx, mx])
-            for ratio in self.output_strides_aspect_ratio[output_stride]:
-                r = ratio ** 0.5
-                out.extend([[cx, cy, mn * r, mn / r], [cx, cy, mn / r, mn * r]])
-        a = torch.tensor(out, dtype=torch.float, device=device)
+        shapes = [(mn, mn), (mx, mx)]
+        for ratio in self.output_strides_aspect_ratio[output_stride]:
+            r = ratio ** 0.5
+            shapes += [(mn * r, mn / r), (mn / r, mn * r)]
+        wh = np.asarray(shapes, dtype=np.float64)                                   # [A, 2]
+        cy = (np.arange(start, height, step, dtype=np.float64) + 0.5) / height       # rows
+        cx = (np.arange(start, width, step, dtype=np.float64) + 0.5) / width         # columns
+        ctr = np.stack(np.meshgrid(cx, cy, indexing="xy"), axis=-1).reshape(-1, 1, 2)  # [H' * W', 1, (cx, cy)], row-major over (y, x)
+        anchors = np.concatenate([np.broadcast_to(ctr, (ctr.shape[0], wh.shape[0], 2)), np.broadcast_to(wh[None], (ctr.shape[0], wh.shape[0], 2))], axis=-1)
+        a = torch.from_numpy(anchors.reshape(-1, 4).astype(np.float32)).to(device)
         return torch.clamp(a, min=0.0, max=1.0) if self.clip else a
 
     @torch.no_grad()

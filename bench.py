@@ -198,7 +198,13 @@ def run(args):
     import cvnets_amd
     from cvnets_amd.ddp import DistributedDataParallel, distributed_init
 
-    if world > 1:
+    # CVH_DDP_FORCE_COLLECTIVES=1 on ONE GPU: a single-rank RCCL group whose (identity) collectives are issued anyway — the N > 1 code path
+    # of this file (rendezvous, in-graph all-reduce, barriers, MAX reduction) executed on the hardware a developer has
+    force = os.environ.get("CVH_DDP_FORCE_COLLECTIVES", "0") == "1"
+    multi = world > 1 or force
+    if multi:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         distributed_init(os.environ.get("CVH_DIST_BACKEND", "nccl"), dev)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cvnets_amd.set_compute_dtype(dtype)
@@ -242,18 +248,22 @@ def run(args):
         else:
             opt.step(sync_hyperparameters=False)  # constant rate in this benchmark: the device-side table was filled by the warm-up steps
 
+    graph_has_allreduce = False  # True: the bucket all-reduces (side stream fork / join) and the optimizer are nodes of the hipGraph
+
     def step():
         nonlocal static_loss
         if graph is not None:
             graph.replay()
-            if world > 1:
+            if graph_has_allreduce:
+                return
+            if multi:
                 ddp.allreduce_flat()
         else:
             zero_grads()
             static_loss = fwd_bwd()
-            if world > 1:
+            if multi:
                 ddp.allreduce_flat()
-        if opt is not None and (graph is None or world > 1):
+        if opt is not None and (graph is None or multi):
             opt_step()
 
     # eager warm-up (also creates every lazily-built tensor before capture); the first step logs the dW GEMM shapes for the kernel probe
@@ -268,7 +278,7 @@ def run(args):
                     static_loss = fwd_bwd()
             else:
                 static_loss = fwd_bwd()
-            if world > 1:
+            if multi:
                 ddp.allreduce_flat()  # replicas stay identical through the warm-up as well
             if opt is not None:
                 opt.step()
@@ -277,23 +287,31 @@ def run(args):
 
     graph_err = None
     if use_graph:
-        try:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                ddp.zero_grad()
-                static_loss = fwd_bwd()
-                if opt is not None and world == 1:
-                    opt_step()
-            graph = g
-        except Exception as e:  # pragma: no cover - reported in the JSON line
-            graph_err = f"{type(e).__name__}: {e}"[:300]
-            graph = None
-            torch.cuda.synchronize()
+        # N > 1: first try the whole step as ONE graph — zero-grad, forward, loss, backward, the bucket all-reduces (RCCL kernels captured
+        # on the side stream: a fork after the last gradient kernel, a join before the optimizer) and the fused AdamW.  If RCCL refuses
+        # to be captured on this stack, fall back to replay + eager all-reduce + eager optimizer (the round-2 path).
+        attempts = [True, False] if (multi and os.environ.get("CVH_GRAPH_ALLREDUCE", "1") != "0") else [False]
+        for in_graph in attempts:
+            try:
+                g = torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    ddp.zero_grad()
+                    static_loss = fwd_bwd()
+                    if in_graph:
+                        ddp.allreduce_flat()
+                    if opt is not None and (not multi or in_graph):
+                        opt_step()
+                graph, graph_has_allreduce, graph_err = g, in_graph, None
+                break
+            except Exception as e:  # pragma: no cover - reported in the JSON line
+                graph_err = f"{type(e).__name__}: {e}"[:300]
+                graph = None
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     st = torch.cuda.current_stream()
@@ -304,11 +322,11 @@ def run(args):
         step()
     e1.record(st)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     wall = time.perf_counter() - t0
     t = torch.tensor([wall], device=dev, dtype=torch.float64)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
     gpu_ms_per_step = e0.elapsed_time(e1) / args.steps
@@ -318,7 +336,8 @@ def run(args):
         out = report(args, world, wall, gpu_ms_per_step)
         headline = args.mode == "small" and args.res == 256 and args.dtype == "bf16"
         out["config"].update({"hipgraph": graph is not None, "dropout": 0.1, "loss": round(loss_val, 4),
-                              "step": "zero_grad+fwd+CE(ls=0.1)+bwd" + ("+allreduce" if world > 1 else "") +
+                              "allreduce": ("in-graph (RCCL, side stream)" if graph_has_allreduce else "after replay (RCCL, side stream)") if multi else None,
+                              "step": "zero_grad+fwd+CE(ls=0.1)+bwd" + ("+allreduce" if multi else "") +
                                       ("" if opt is None else ("+AdamW(torch fused)" if args.torch_optimizer else "+AdamW(cvh_adamw_multi)"))})
         if graph_err:
             out["config"]["hipgraph_error"] = graph_err
@@ -347,7 +366,7 @@ def run(args):
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

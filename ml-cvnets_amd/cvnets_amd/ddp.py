@@ -15,9 +15,15 @@ Design for the 8-GPU xGMI mesh (7 links x ~153 GB/s per GPU, point-to-point):
     of torch >= 2 and of the reference's engine) gets them copied back in and re-pointed before every reduction;
   * float buffers (BatchNorm running statistics) are made views of ONE flat tensor at construction, so the per-forward rank-0
     broadcast of main_train.py's DDP (``broadcast_buffers``) is a single collective with no gather / scatter copies.
+
+ORDER REQUIREMENT: wrap the model BEFORE anything records raw pointers into it — ``optim.EMABuffers``, a hipGraph capture, the fused
+AdamW plan — because the constructor re-points gradient and float-buffer storage into the flat tensors (cvnets_amd/launch.py wraps right
+after ``model.to(device)``, as main_train.py does).  A later ``module.to()`` / ``.float()`` detaches the buffer views; ``forward`` checks
+that and falls back to per-buffer broadcasts.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional
 
@@ -73,11 +79,17 @@ class _Bucket:
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, bucket_cap_mb: float = 25.0, overlap: bool = True, broadcast_buffers: bool = True,
-                 process_group=None):
+                 process_group=None, force_collectives: Optional[bool] = None):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        # a single-rank group normally skips every collective; `force_collectives` (or CVH_DDP_FORCE_COLLECTIVES=1) issues them anyway —
+        # a world-size-1 RCCL all-reduce is an identity that still runs the communicator, the side stream and the event ordering
+        # (tests/test_rccl_gpu.py executes the whole GPU side of this file on one GPU that way)
+        if force_collectives is None:
+            force_collectives = os.environ.get("CVH_DDP_FORCE_COLLECTIVES", "0") == "1"
+        self.active = dist.is_initialized() and (self.world > 1 or bool(force_collectives))
         self.overlap = overlap
         self.broadcast_buffers = broadcast_buffers
         params = [p for p in module.parameters() if p.requires_grad]
@@ -97,7 +109,7 @@ class DistributedDataParallel(nn.Module):
                 b.data = self.flat_buffers[off: off + b.numel()].view_as(b)
                 off += b.numel()
         # parameters + buffers start identical on every rank (DDP ctor broadcast)
-        if self.world > 1:
+        if self.active:
             for t in list(module.parameters()) + [b for b in module.buffers()]:
                 dist.broadcast(t.data, src=0, group=self.pg)
         self._avg_op = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(self.pg) == "nccl") else None
@@ -118,15 +130,34 @@ class DistributedDataParallel(nn.Module):
             for p in b.params:
                 self._bucket_of[p] = b
                 p.register_post_accumulate_grad_hook(self._hook)
-        self._callback_queued = False
+        self._callback_task = None  # autograd graph-task id whose end-of-backward `finish` is queued (a dropped callback cannot go stale)
         self.hooks_enabled = True
+        self._buf_span = None
+        if self.flat_buffers is not None and fbufs:
+            self._buf_span = (fbufs[0], fbufs[-1])
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """torch DDP's contract: backward passes inside the context accumulate locally, the first backward after it reduces the
+        accumulated gradients (gradient accumulation, engine/training_engine.py:221,289: `accum_freq` micro-steps per update)."""
+        prev = self.hooks_enabled
+        self.hooks_enabled = False
+        try:
+            yield
+        finally:
+            self.hooks_enabled = prev
 
     # ---- autograd-driven path (eager) --------------------------------------------------------
     def _hook(self, p: nn.Parameter):
-        if not self.hooks_enabled or self.world == 1:
+        if not self.hooks_enabled or not self.active:
             return
-        if not self._callback_queued:
-            self._callback_queued = True
+        tid = torch._C._current_graph_task_id()
+        if self._callback_task != tid:
+            if self._callback_task is not None:  # the backward that queued `finish` died before it ran: start from a clean slate
+                for b in self.buckets:
+                    b.work = None
+                    b.pending = len(b.params)
+            self._callback_task = tid
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
         b = self._bucket_of[p]
         b.pending -= 1
@@ -162,12 +193,14 @@ class DistributedDataParallel(nn.Module):
         if self.use_side_stream:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         self._average()
-        self._callback_queued = False
+        self._callback_task = None
 
     # ---- explicit path (after a hipGraph replay) ---------------------------------------------
     def allreduce_flat(self):
-        if self.world == 1:
+        if not self.active:
             return
+        from . import ops
+        ops.finish_backward()  # deferred dW reductions / side-stream joins of a backward whose callback was lost must not leak in
         for b in self.buckets:
             self._launch(b)
         for b in self.buckets:
@@ -186,9 +219,16 @@ class DistributedDataParallel(nn.Module):
     def grad_bytes(self) -> int:
         return sum(b.numel for b in self.buckets) * 4
 
+    def _buffers_still_flat(self) -> bool:
+        """the float buffers were re-pointed into `flat_buffers` at construction; a later `module.to()` / `.float()` detaches them"""
+        if self._buf_span is None:
+            return False
+        lo, hi = self.flat_buffers.data_ptr(), self.flat_buffers.data_ptr() + self.flat_buffers.numel() * self.flat_buffers.element_size()
+        return all(lo <= b.data_ptr() < hi for b in self._buf_span)
+
     def forward(self, *args, **kwargs):
-        if self.broadcast_buffers and self.world > 1 and self.training:
-            if self.flat_buffers is not None:
+        if self.broadcast_buffers and self.active and self.training:
+            if self.flat_buffers is not None and self._buffers_still_flat():
                 dist.broadcast(self.flat_buffers, src=0, group=self.pg)  # the buffers ARE views of this tensor
             else:
                 for b in self.module.buffers():
@@ -224,8 +264,11 @@ class _AllGatherWithGrad(torch.autograd.Function):
         return out, None
 
 
-def gather_all_features(features: torch.Tensor, group=None) -> torch.Tensor:
-    """[N, d] on every rank -> [W*N, d], differentiable (ContrastiveLossClip, contrastive_loss_clip.py:144-172)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def gather_all_features(features: torch.Tensor, group=None, force: Optional[bool] = None) -> torch.Tensor:
+    """[N, d] on every rank -> [W*N, d], differentiable (ContrastiveLossClip, contrastive_loss_clip.py:144-172).  `force` (or
+    CVH_DDP_FORCE_COLLECTIVES=1) issues the collectives on a single-rank group too (identity; executes the RCCL path on one GPU)."""
+    if force is None:
+        force = os.environ.get("CVH_DDP_FORCE_COLLECTIVES", "0") == "1"
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return features
     return _AllGatherWithGrad.apply(features, group)

@@ -82,6 +82,7 @@ class InvertedResidual(nn.Module):
         mods = self.block._modules
         if "exp_1x1" not in mods or self.dilation != 1:
             return False
+        modes = set()
         for name in ("exp_1x1", "conv_3x3", "red_1x1"):
             blk = mods[name].block
             conv, norm = getattr(blk, "conv", None), getattr(blk, "norm", None)
@@ -92,6 +93,14 @@ class InvertedResidual(nn.Module):
                 return False
             if conv.weight.shape[1] % 8 and conv.groups == 1:
                 return False
+            if conv.weight.shape[0] % 8:  # hidden / output widths: the fused kernels move 8-channel (16 B) groups
+                return False
+            modes.add((bool(norm.training), bool(norm.track_running_stats)))
+        dwc = mods["conv_3x3"].block.conv
+        if tuple(dwc.kernel_size) != (3, 3) or tuple(dwc.padding) != (1, 1) or dwc.groups != dwc.weight.shape[0]:
+            return False  # InvertedResidualFn hard-codes the depthwise 3x3 / pad 1 geometry
+        if len(modes) != 1:
+            return False  # partially frozen BatchNorm: the fused node takes ONE train / eval mode for all three norms
         return mods["red_1x1"].block._modules.get("act") is None
 
     def __repr__(self) -> str:

@@ -401,12 +401,14 @@ def _colsum(x2d: torch.Tensor, rows: int, C: int, sink: Optional[torch.Tensor] =
 # backward pass (autograd end-of-backward callback).  Captured into a hipGraph this becomes two parallel branches per layer.
 _ASYNC_PARAM_GRADS = os.environ.get("CVH_ASYNC_DW", "1") != "0"
 _side_streams = {}
-_side_join_queued = False
+# id of the autograd graph task (one per backward call) whose end-of-backward callback is queued, or None.  Tied to the task id rather
+# than a bare flag: autograd DROPS queued callbacks when a backward raises (an OOM the engine skips, a kernel error), and a stale "already
+# queued" flag would make every later backward skip its join + deferred reductions — training on with missing gradients.
+_queued_task_id = None
 
 
 def _param_grad_stream(device):
     """returns the side stream (already made to wait for everything queued so far on the current stream) or None"""
-    global _side_join_queued
     if not (_ASYNC_PARAM_GRADS and _INPLACE_PARAM_GRADS):
         return None
     side = _side_streams.get(device)
@@ -419,8 +421,8 @@ def _param_grad_stream(device):
 
 
 def _join_param_grad_stream():
-    global _side_join_queued
-    _side_join_queued = False
+    global _queued_task_id
+    _queued_task_id = None
     for dev, side in _side_streams.items():
         torch.cuda.current_stream(dev).wait_stream(side)
     _flush_deferred_reductions()
@@ -435,14 +437,28 @@ _pending_reductions = []
 
 
 def _ensure_backward_callback() -> bool:
-    global _side_join_queued
-    if not _side_join_queued:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_join_param_grad_stream)
-        except RuntimeError:  # not inside a backward pass
-            return False
-        _side_join_queued = True
+    global _queued_task_id
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:  # not inside a backward pass (direct Function.backward call in a test)
+        return False
+    if tid != _queued_task_id:
+        if _queued_task_id is not None or _pending_reductions:
+            # the backward that queued them died before its callback ran: its partial buffers are gone, its gradients are void
+            _pending_reductions.clear()
+        torch.autograd.Variable._execution_engine.queue_callback(_join_param_grad_stream)
+        _queued_task_id = tid
     return True
+
+
+def finish_backward() -> None:
+    """Idempotent join of the parameter-gradient side stream + flush of the deferred reductions.  The end-of-backward callback normally
+    does both; the consumers of .grad (fused AdamW, DDP.allreduce_flat) call this first so that state can never leak across steps."""
+    if torch._C._current_graph_task_id() >= 0:
+        return  # still inside the backward pass: its own callback will run
+    if _queued_task_id is not None or _pending_reductions:
+        # a callback that never ran (backward raised): the queued reductions belong to a void backward — drop them, but re-join the stream
+        _pending_reductions.clear()
+        _join_param_grad_stream()
 
 
 def defer_reduce(part, out, rows, row_stride, n_out, *, kind=0, N=0, Ktot=0, Cin=0, Cin_real=0, khw=1, scale=1.0, part_offset=0) -> bool:
@@ -464,11 +480,25 @@ def _flush_deferred_reductions() -> None:
         by_dev.setdefault(item[1].device, []).append(item)
     _pending_reductions.clear()
     for dev, items in by_dev.items():
-        arr = (_lib.ReduceDesc * len(items))(*[it[0] for it in items])
+        # cvh_reduce_multi adds into `out` without atomics, one workgroup set per descriptor: two descriptors with the SAME destination
+        # (a shared weight, a module applied twice in one graph) must not share a launch — later duplicates go to later launches,
+        # which the stream serialises
+        rounds = []
+        for it in items:
+            key = it[2].data_ptr()
+            for seen, lst in rounds:
+                if key not in seen:
+                    seen.add(key)
+                    lst.append(it)
+                    break
+            else:
+                rounds.append(({key}, [it]))
         with torch.cuda.device(dev):
-            for it in items:
-                it[1].record_stream(torch.cuda.current_stream(dev))
-            _lib.call("cvh_reduce_multi", arr, len(items), _stream())
+            for _, lst in rounds:
+                arr = (_lib.ReduceDesc * len(lst))(*[it[0] for it in lst])
+                for it in lst:
+                    it[1].record_stream(torch.cuda.current_stream(dev))
+                _lib.call("cvh_reduce_multi", arr, len(lst), _stream())
 
 
 _FOLD_BIAS = os.environ.get("CVH_FOLD_BIAS", "1") != "0"

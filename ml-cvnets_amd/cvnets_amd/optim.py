@@ -147,6 +147,9 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, inv_grad_scale: Optional[torch.Tensor] = None, sync_hyperparameters: bool = True):
         loss = closure() if closure is not None else None
+        ops.finish_backward()  # side-stream dW work / deferred reductions of a backward whose end-of-backward callback was lost
+        if not any(p.grad is not None for g in self.param_groups for p in g["params"]):
+            return loss  # torch.optim.AdamW.step() with no gradients anywhere is a no-op
         plan = self._plan
         if plan is None or not self._valid(plan):
             plan = self._build()  # carries the moments of the previous plan over, parameter by parameter

@@ -684,6 +684,9 @@ def run_detection_case(outdir, name="ssd_mobilevit_s_160_b2", batch=2, res=160):
 
 
 LARGE_CASES = [("mobilevit_s_256_b16", "small", 16, 256)]        # the BASELINE configuration at a batch where train-mode BatchNorm noise is small
+# the largest batch the 62 GB authoring container holds through the reference's unfused fp32 graph (~0.4 GB of saved activations per image):
+# one train step at the benchmark resolution for tests/test_bench_scale_gpu.py (`--b64`)
+BENCH_SCALE_CASES = [("mobilevit_s_256_b64", "small", 64, 256)]
 LARGE_VIT_CASES = [("vit_tiny_224_b16", "tiny", 16, 224)]
 LARGE_V2_CASES = [("mobilevitv2_w100_256_b16", 1.0, 16, 256)]
 
@@ -704,6 +707,10 @@ if __name__ == "__main__":
     if "--endpoints" in sys.argv:
         run_endpoints_case(outdir)
         run_endpoints_case(outdir, name="mobilevit_xxs_os16_64_b2", mode="xx_small", output_stride=16, batch=2, res=64)
+        sys.exit(0)
+    if "--b64" in sys.argv:
+        for c in BENCH_SCALE_CASES:
+            run_case(*c, outdir)
         sys.exit(0)
     if "--large" in sys.argv:  # large-batch bf16 parity fixtures only (tests/test_bf16_parity_gpu.py)
         for c in LARGE_CASES:

@@ -6,3 +6,10 @@ the detection symbols are inert placeholders for import-time name resolution.
 """
 from . import ops  # noqa: F401
 __version__ = "0.0.shim"
+
+
+def __getattr__(name):  # PEP 562: anything else the reference's data / detection stack names at import time is an inert placeholder
+    if name.startswith("__"):
+        raise AttributeError(name)
+    from autostub import _make
+    return _make(name)

@@ -1,0 +1,78 @@
+"""Regression tests for the round-2 advisor findings on the deferred-reduction machinery of cvnets_amd/ops.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_shared_layer_applied_twice_inplace_grads():
+    """One layer used twice in a graph queues two deferred reductions with the SAME destination; cvh_reduce_multi adds without atomics,
+    so they must not share a launch.  (LinearLayer.forward, cvnets/layers/linear_layer.py:74-91, applied twice = a siamese / shared-weight
+    module; also a depthwise-free conv applied twice.)"""
+    import cvnets_amd
+    from cvnets_amd import ops
+    torch.manual_seed(0)
+    lin = cvnets_amd.LinearLayer(192, 192, bias=True).cuda()
+    x = torch.randn(4096, 192, device="cuda")
+    w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
+    # fp32 torch reference of y = L(L(x)); loss = sum(y * t)
+    t = torch.randn(4096, 192, device="cuda")
+    wr, br = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = torch.nn.functional.linear(torch.nn.functional.linear(x, wr, br), wr, br)
+    (yr * t).sum().backward()
+    cvnets_amd.set_compute_dtype(torch.float32)
+    ops.set_inplace_param_grads(True)
+    try:
+        for _ in range(3):  # several rounds: a lost contribution is a race, not a certainty
+            lin.weight.grad = torch.zeros_like(lin.weight)
+            lin.bias.grad = torch.zeros_like(lin.bias)
+            y = lin(lin(x))
+            (y * t).sum().backward()
+            torch.cuda.synchronize()
+            assert torch.allclose(lin.weight.grad, wr.grad, rtol=2e-4, atol=2e-3 * float(wr.grad.abs().max()))
+            assert torch.allclose(lin.bias.grad, br.grad, rtol=2e-4, atol=2e-3 * float(br.grad.abs().max()))
+    finally:
+        ops.set_inplace_param_grads(False)
+        cvnets_amd.set_compute_dtype(None)
+
+
+def test_failed_backward_does_not_poison_the_next_one():
+    """A backward that raises drops autograd's end-of-backward callback; the queued state must not leak into later backward passes
+    (training_engine.py:709-723 catches exceptions — e.g. out-of-memory — and carries on)."""
+    import cvnets_amd
+    from cvnets_amd import ops
+    torch.manual_seed(0)
+    lin = cvnets_amd.LinearLayer(128, 128, bias=True).cuda()
+    x = torch.randn(2048, 128, device="cuda")
+    xg = x.clone().requires_grad_(True)  # Boom's backward only runs if its input needs a gradient
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a):
+            return a.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("simulated failure inside backward")
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    ops.set_inplace_param_grads(True)
+    try:
+        lin.weight.grad = torch.zeros_like(lin.weight)
+        lin.bias.grad = torch.zeros_like(lin.bias)
+        # the layer's dW is queued first (its node runs before Boom's), then the backward dies
+        with pytest.raises(RuntimeError, match="simulated failure"):
+            lin(Boom.apply(xg)).sum().backward()
+        torch.cuda.synchronize()
+        lin.weight.grad.zero_()
+        lin.bias.grad.zero_()
+        lin(x).sum().backward()
+        torch.cuda.synchronize()
+        want_w = torch.ones(2048, 128, device="cuda").t() @ x
+        assert torch.allclose(lin.weight.grad, want_w, rtol=1e-4, atol=1e-3 * float(want_w.abs().max()))
+        assert torch.allclose(lin.bias.grad, torch.full((128,), 2048.0, device="cuda"))
+        assert not ops._pending_reductions and ops._queued_task_id is None
+        ops.finish_backward()  # idempotent
+    finally:
+        ops.set_inplace_param_grads(False)
+        cvnets_amd.set_compute_dtype(None)

@@ -14,7 +14,8 @@ def timeit(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-shapes = [("l1", 128, 64, 128, 128, 1), ("l2.1", 128, 256, 64, 64, 1), ("l2.0", 128, 128, 128, 128, 2)]
+BB = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+shapes = [("l1", BB, 64, 128, 128, 1), ("l2.1", BB, 256, 64, 64, 1), ("l2.0", BB, 128, 128, 128, 2), ("l3.0", BB, 256, 64, 64, 2)]
 for name, B, C, H, W, S in shapes:
     Ho, Wo = (H - 1) // S + 1, (W - 1) // S + 1
     y1 = torch.randn(B, H, W, C, device=dev).to(dt)

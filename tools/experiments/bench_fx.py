@@ -11,7 +11,7 @@ def timeit(f, n=5):
     for _ in range(n): f()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (M, K, N) in [(4194304, 64, 128), (4194304, 64, 256), (16777216, 32, 64)]:
+for (M, K, N) in [(4194304, 64, 128), (4194304, 64, 256), (16777216, 32, 64), (1048576, 96, 256)]:
     a = torch.randn(M, K, device=dev).bfloat16()
     w = torch.randn(N, K, device=dev) * 0.1
     wp = ops.pack_weight(w.view(N, K, 1, 1), torch.bfloat16, 0) if hasattr(ops, "pack_weight") else None

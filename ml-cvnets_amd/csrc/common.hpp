@@ -206,11 +206,35 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// One 32-bit hash word serves TWO consecutive elements (16 uniform bits each, keep <=> u16 >= round(p * 2^16)): the keep decision
+// costs one mix32 per element pair instead of three per element (the integer multiplies are quarter rate — in the token GEMM epilogues
+// the generator used to be the largest single VALU item).  The drop probability is p rounded to 2^-16 (0.1 -> 0.100006).
+struct DropKey { uint32_t key, thr; };
+__device__ __forceinline__ DropKey drop_key(uint64_t seed, uint32_t stream, float p) {
+  DropKey k;
+  k.key = mix32(stream * 0x9e3779b9u + (uint32_t)seed) ^ (uint32_t)(seed >> 32);
+  k.thr = (uint32_t)(p * 65536.0f + 0.5f);
+  return k;
+}
+// pair = element index >> 1; hi = (uint32_t)(pair >> 32) * 0x85ebca6bu (zero below 2^33 elements)
+__device__ __forceinline__ uint32_t drop_word(const DropKey& k, uint32_t pair_lo, uint32_t hi) { return mix32(pair_lo ^ k.key ^ hi); }
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t stream, uint64_t idx, float p, float inv_keep) {
-  uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + stream * 0x9e3779b9u + (uint32_t)seed));
-  h = mix32(h ^ (uint32_t)(seed >> 32));
-  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-  return u >= p ? inv_keep : 0.0f;
+  const DropKey k = drop_key(seed, stream, p);
+  const uint64_t pair = idx >> 1;
+  const uint32_t h = drop_word(k, (uint32_t)pair, (uint32_t)(pair >> 32) * 0x85ebca6bu);
+  const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return u >= k.thr ? inv_keep : 0.0f;
+}
+// v[0..7] *= keep-scale of elements idx8 .. idx8 + 7 (idx8 % 8 == 0): the same masks as eight dropout_scale calls
+__device__ __forceinline__ void dropout_scale8(const DropKey& k, uint64_t idx8, float inv_keep, float* v) {
+  const uint64_t pair = idx8 >> 1;
+  const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32) * 0x85ebca6bu;  // pair .. pair + 3 share the high word (idx8 % 8 == 0)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = drop_word(k, lo + q, hi);
+    v[2 * q] *= (h & 0xffffu) >= k.thr ? inv_keep : 0.0f;
+    v[2 * q + 1] *= (h >> 16) >= k.thr ? inv_keep : 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,6 +358,7 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_DW_XCD 4        /* depthwise: XCD-contiguous block mapping on/off */
 #define CVH_TUNE_BIG_GEMM 5    /* 1: transformer-sized linears use the 128x128 direct-to-LDS kernel (gemm_big.hip), 0: conv_gemm */
 #define CVH_TUNE_COLRED_ROWS 6 /* cap on the number of partial rows (= workgroups) of the column-reduction kernels */
+#define CVH_TUNE_LN_PER_ROW 12 /* 1: LayerNorm on the one-row-per-wave kernels instead of the grouped ones */
 #define CVH_TUNE_NO_SKINNY 9   /* 1: pointwise dW of small tiles stays on gemm_tn_kernel */
 #define CVH_TUNE_SKINNY_WGS 10 /* workgroups of gemm_tn_skinny_kernel (0: 512) */
 #define CVH_TUNE_NO_WAVE_PRIVATE 11 /* 1: single-K-step BatchNorm-link GEMMs keep the cooperative (barrier) staging */

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     bias_r[f] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
   }
 
-  unsigned long long seed = 0;
-  if (p.drop_p > 0.f) seed = *p.seed;
+  DropKey dkey = {0u, 0u};
+  if (p.drop_p > 0.f) dkey = drop_key(*p.seed, p.stream_id, p.drop_p);
   const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
   // ---- software pipeline across M tiles: the A/B registers of tile t+1 are requested before tile t's epilogue ----
@@ -331,10 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
               v8_unpack(v8_load<T>(reinterpret_cast<const T*>(p.actgrad_aux) + o), a);
               act_grad8_mul(v, a, p.actgrad_act);
             }
-            if (p.drop_p > 0.f) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(seed, p.stream_id, o + j, p.drop_p, inv_keep);
-            }
+            if (p.drop_p > 0.f) dropout_scale8(dkey, o, inv_keep, v);  // o % 8 == 0: N % 8 == 0, 8-column chunks
             if (p.residual) {
               float rr[8];
               v8_unpack(v8_load<T>(reinterpret_cast<const T*>(p.residual) + o), rr);

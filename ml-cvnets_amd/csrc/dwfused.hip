@@ -210,15 +210,35 @@ __global__ __launch_bounds__(256, 2) void dwf_fwd_kernel(DwfParams p) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward (dX + dW + BatchNorm-backward statistics in one pass)
 // ---------------------------------------------------------------------------------------------------------------------------
+// z = act(y), gp = act'(y) of eight channels from ONE sigmoid per element (SiLU: z = y s, act' = s (1 + y (1 - s)))
+__device__ __forceinline__ void act_fwd_grad8(const float* y, int act, float* z, float* gp) {
+  if (act == CVH_ACT_SILU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = sigmoidf_(y[j]);
+      z[j] = y[j] * s;
+      gp[j] = s * (1.0f + y[j] * (1.0f - s));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { z[j] = act_fwd(y[j], act); gp[j] = act_grad(y[j], act); }
+  }
+}
+
+// Both products of the backward pass run over the SAME (input pixel p, tap d) pairs:
+//     dz[p]  = sum_d dy[p - d] * w[d]          (input gradient)
+//     dW[d] += sum_p dy[p - d] * z[p]          (weight gradient, re-indexed from sum_o dy[o] * z[o + d] by p = o + d)
+// so every dy value fetched from the LDS tile feeds two FMAs, z = act(bn(x_raw)) is needed only at the lane's OWN pixels — computed in
+// registers from the x_raw values the epilogue needs anyway (act' shares its sigmoid) — and the z tile with its halo (a second LDS tile,
+// 1.4x the activation work, a second pass of 18 LDS reads + unpacks per lane) does not exist.
 template <typename T, int S>
 __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
   using TL = DwfTile<S>;
   constexpr int PITCH = dwf_pitch<T>();
-  constexpr int NZ = TL::IH * TL::IW, ND = TL::DH * TL::DW;
-  constexpr int NLZ = (NZ * 8 + 255) / 256, NLD = (ND * 8 + 255) / 256;
+  constexpr int ND = TL::DH * TL::DW;
+  constexpr int NLD = (ND * 8 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* zt = reinterpret_cast<T*>(smem_raw);                 // [NZ][PITCH]  z = act(scale*x_raw + shift), zero outside the image
-  T* dt = zt + NZ * PITCH;                                // [ND][PITCH]  dy, zero outside the image
+  T* dt = reinterpret_cast<T*>(smem_raw);                  // [ND][PITCH]  dy, zero outside the image
   float* red = reinterpret_cast<float*>(dt + ND * PITCH);  // [2][CC] statistics
   float* dwl = red + 2 * DWF_CC;                          // [9][CC] dW of this workgroup
   float* wl = dwl + 9 * DWF_CC;                           // [9][CC] weights
@@ -258,25 +278,39 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
 
   const int t_begin = row_id, t_end = p.ntiles, t_step = gridDim.x / p.chunks;
 
-  // g_in = dz * act'(scale*x_raw + shift) for one pixel, stored; statistics of the stored value
-  auto emit = [&](const float* dz, const V8<T>& xraw, int b, int hi, int wi) __attribute__((always_inline)) {
-    if (hi < p.H && wi < p.W && ch_ok) {
-      const size_t o = ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch;
-      float xv[8], g[8], sc[8], sh[8];
-      v8_unpack(xraw, xv);
-      lds_f8(cst + 2 * DWF_CC + cl * 8, sc);
-      lds_f8(cst + 3 * DWF_CC + cl * 8, sh);
-      float yh[8];
+  // z, act' and xhat of one own pixel from its raw value (zeros for a pixel outside the image: it then contributes nothing to dW)
+  auto prep = [&](const V8<T>& xraw, bool ok, float* z, float* gp) __attribute__((always_inline)) {
+    float xv[8], sc[8], sh[8], yh[8];
+    v8_unpack(xraw, xv);
+    lds_f8(cst + 2 * DWF_CC + cl * 8, sc);
+    lds_f8(cst + 3 * DWF_CC + cl * 8, sh);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { g[j] = dz[j]; yh[j] = xv[j] * sc[j] + sh[j]; }
-      if (!(p.dbg & 4)) act_grad8_mul(g, yh, p.in_act);
-      V8<T> ov;
-      v8_pack(g, ov);
-      v8_store<T>(gi + o, ov);
-      float gr[8], mu[8], is[8];
-      v8_unpack(ov, gr);
+    for (int j = 0; j < 8; ++j) yh[j] = xv[j] * sc[j] + sh[j];
+    if (p.dbg & 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { z[j] = yh[j]; gp[j] = 1.f; }
+    } else {
+      act_fwd_grad8(yh, p.in_act, z, gp);
+    }
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = 0.f;
+    }
+  };
+  // g_in = dz * act' stored; statistics of the stored value
+  auto emit = [&](const float* dz, const float* gp, const V8<T>& xraw, bool ok, int b, int hi, int wi) __attribute__((always_inline)) {
+    if (ok) {
+      float g[8], xv[8], mu[8], is[8];
+      v8_unpack(xraw, xv);
       lds_f8(cst + cl * 8, mu);
       lds_f8(cst + DWF_CC + cl * 8, is);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = (p.dbg & 4) ? dz[j] : dz[j] * gp[j];
+      V8<T> ov;
+      v8_pack(g, ov);
+      v8_store<T>(gi + ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, ov);
+      float gr[8];
+      v8_unpack(ov, gr);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s1[j] += gr[j]; s2[j] += gr[j] * (xv[j] - mu[j]) * is[j]; }
     }
@@ -289,20 +323,12 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
     const int b = t1 / p.tiles_h;
     const int ho0 = th * TL::OH, wo0 = tw * TL::OW;   // first owned output pixel
     const int hi0 = ho0 * S, wi0 = wo0 * S;           // first input pixel of the tile
-    // z tile origin: (hi0 - 1, wi0 - 1);  dy tile origin: stride 1: (ho0 - 1, wo0 - 1), stride 2: (ho0, wo0)
+    // dy tile origin: stride 1: (ho0 - 1, wo0 - 1), stride 2: (ho0, wo0)
     const int dh0 = S == 1 ? ho0 - 1 : ho0, dw0 = S == 1 ? wo0 - 1 : wo0;
 
     {
-      V8<T> rz[NLZ], rg[NLD], ry[NLD];
-      bool zok[NLZ], dok[NLD];
-#pragma unroll
-      for (int i = 0; i < NLZ; ++i) {
-        const int px = (tid + i * 256) >> 3;
-        const int pr = px / TL::IW, pc = px - pr * TL::IW;
-        const int hi = hi0 - 1 + pr, wi = wi0 - 1 + pc;
-        zok[i] = px < NZ && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W && ch_ok;
-        rz[i] = v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, zok[i]);
-      }
+      V8<T> rg[NLD], ry[NLD];
+      bool dok[NLD];
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int px = (tid + i * 256) >> 3;
@@ -314,92 +340,74 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
         ry[i] = v8_load_clamped<T>(dy2src ? yo : go, o, dok[i]);
       }
       __syncthreads();  // previous tile fully consumed (first iteration: staged vectors visible)
-      {
-        Coef8 kz;
-        lds_f8(cst + 2 * DWF_CC + cl * 8, kz.a);
-        lds_f8(cst + 3 * DWF_CC + cl * 8, kz.b);
+      Coef8 kd;
+      lds_f8(cst + 4 * DWF_CC + cl * 8, kd.a);
+      lds_f8(cst + 5 * DWF_CC + cl * 8, kd.b);
+      lds_f8(cst + 6 * DWF_CC + cl * 8, kd.c);
 #pragma unroll
-        for (int i = 0; i < NLZ; ++i) {
-          const int px = (tid + i * 256) >> 3;
-          if (px < NZ) v8_store<T>(zt + px * PITCH + cl * 8, (p.dbg & 8) ? rz[i] : xf_apply<T>(rz[i], rz[i], kz, 1, p.in_act, zok[i]));
-        }
-      }
-      {
-        Coef8 kd;
-        lds_f8(cst + 4 * DWF_CC + cl * 8, kd.a);
-        lds_f8(cst + 5 * DWF_CC + cl * 8, kd.b);
-        lds_f8(cst + 6 * DWF_CC + cl * 8, kd.c);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          const int px = (tid + i * 256) >> 3;
-          if (px < ND) {
-            V8<T> v = v8_mask(rg[i], dok[i]);
-            if (dy2src) v = xf_apply<T>(rg[i], ry[i], kd, 2, 0, dok[i]);
-            v8_store<T>(dt + px * PITCH + cl * 8, v);
-          }
+      for (int i = 0; i < NLD; ++i) {
+        const int px = (tid + i * 256) >> 3;
+        if (px < ND) {
+          V8<T> v = v8_mask(rg[i], dok[i]);
+          if (dy2src) v = xf_apply<T>(rg[i], ry[i], kd, 2, 0, dok[i]);
+          v8_store<T>(dt + px * PITCH + cl * 8, v);
         }
       }
     }
     __syncthreads();
 
     if (S == 1) {
-      const int r = pl >> 2, q = pl & 3;  // row r, columns 4q .. 4q+3 (tile coordinates); dy / z tiles are offset by (-1, -1)
-      // ---- dX: dz[r][c] = sum_{kh,kw} dy[r + 1 - kh][c + 1 - kw] * w[kh][kw]  ->  dy tile rows r + dh (kh = 2 - dh), cols c + (2 - kw) ----
-      // x_raw at the lane's own pixels (for act' and xhat in the epilogue): requested now, consumed after the dX stencil
+      const int r = pl >> 2, q = pl & 3;  // row r, columns 4q .. 4q+3 (tile coordinates); the dy tile is offset by (-1, -1)
+      const int hi = hi0 + r;
       V8<T> xc[4];
+      bool pok[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int hi = hi0 + r, wi = wi0 + q * 4 + t;
-        xc[t] = v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, hi < p.H && wi < p.W && ch_ok);
+        const int wi = wi0 + q * 4 + t;
+        pok[t] = hi < p.H && wi < p.W && ch_ok;
+        xc[t] = v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, pok[t]);
       }
-      float acc[4][8];
+      // two halves of two adjacent pixels each (z, act', xhat and the accumulators of all four pixels at once do not fit the register
+      // file next to the 72 dW accumulators): a half's window is 4 dy columns per row
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int half = 0; half < 2; ++half) {
+        float z[2][8], gp[2][8], acc[2][8];
+        __builtin_amdgcn_sched_barrier(0);  // keep the halves apart: interleaved, their live ranges spill
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-#pragma unroll 1
-      for (int dh = (p.dbg & 2) ? 3 : 0; dh < 3; ++dh) {
-        float wr[3][8];
+        for (int t = 0; t < 2; ++t) {
+          prep(xc[half * 2 + t], pok[half * 2 + t], z[t], gp[t]);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) lds_f8(wl + ((2 - dh) * 3 + kw) * DWF_CC + cl * 8, wr[kw]);
-        const T* rowp = dt + ((r + dh) * TL::DW + q * 4) * PITCH + cl * 8;
+          for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+        }
+        // pixel (r, c): dy[r + 1 - kh][c + 1 - kw] = dy-tile row r + dh (kh = 2 - dh), column c + dwc (kw = 2 - dwc)
 #pragma unroll
-        for (int cix = 0; cix < 6; ++cix) {
-          float f[8];
-          v8_unpack(v8_load<T>(rowp + cix * PITCH), f);
+        for (int dh = 0; dh < 3; ++dh) {
+          float wr[3][8];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int dwc = cix - t;  // dy col = c - 1 + dwc, kw = 2 - dwc
-            if (dwc >= 0 && dwc < 3) {
+          for (int kw = 0; kw < 3; ++kw) lds_f8(wl + ((2 - dh) * 3 + kw) * DWF_CC + cl * 8, wr[kw]);
+          const T* rowp = dt + ((r + dh) * TL::DW + q * 4 + half * 2) * PITCH + cl * 8;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) acc[t][j] += f[j] * wr[2 - dwc][j];
+          for (int cix = 0; cix < 4; ++cix) {
+            float f[8];
+            v8_unpack(v8_load<T>(rowp + cix * PITCH), f);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int dwc = cix - t;
+              if (dwc >= 0 && dwc < 3) {
+                if (!(p.dbg & 2)) {
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) acc[t][j] += f[j] * wr[2 - dwc][j];
+                }
+                if (!(p.dbg & 1)) {
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) dwa[(2 - dh) * 3 + (2 - dwc)][j] += f[j] * z[t][j];
+                }
+              }
             }
           }
         }
-      }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) emit(acc[t], xc[t], b, hi0 + r, wi0 + q * 4 + t);
-      // ---- dW[kh][kw] += dy[r][c] * z[r - 1 + kh][c - 1 + kw]  (dy tile (r+1, c+1); z tile rows r + kh, cols c + kw) ----
-      if (p.dbg & 1) continue;
-      float dyc[4][8];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) v8_unpack(v8_load<T>(dt + ((r + 1) * TL::DW + q * 4 + t + 1) * PITCH + cl * 8), dyc[t]);
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const T* rowp = zt + ((r + kh) * TL::IW + q * 4) * PITCH + cl * 8;
-#pragma unroll
-        for (int cix = 0; cix < 6; ++cix) {
-          float f[8];
-          v8_unpack(v8_load<T>(rowp + cix * PITCH), f);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int kw = cix - t;
-            if (kw >= 0 && kw < 3) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) dwa[kh * 3 + kw][j] += f[j] * dyc[t][j];
-            }
-          }
-        }
+        for (int t = 0; t < 2; ++t) emit(acc[t], gp[t], xc[half * 2 + t], pok[half * 2 + t], b, hi, wi0 + q * 4 + half * 2 + t);
       }
     } else {
       // stride 2: lane = quad row qr (0..7), quads 2qc, 2qc+1.  Quad (qh, qw) = inputs (2qh + {0,1}, 2qw + {0,1}) from dy[qh + {0,1}][qw + {0,1}]
@@ -410,14 +418,23 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
 #pragma unroll
         for (int c2 = 0; c2 < 3; ++c2) v8_unpack(v8_load<T>(dt + ((qr + a) * TL::DW + 2 * qc + c2) * PITCH + cl * 8), d[a][c2]);
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph)
+      for (int ph = 0; ph < 2; ++ph) {
+        const int hi = hi0 + 2 * qr + ph;
+        V8<T> xc[4];   // the four pixels of this input row: (quad qq, parity pw)
+        bool pok[4];
 #pragma unroll
-        for (int pw = 0; pw < 2; ++pw) {
-          float acc[2][8];
+        for (int e = 0; e < 4; ++e) {
+          const int wi = wi0 + 2 * (2 * qc + (e >> 1)) + (e & 1);
+          pok[e] = hi < p.H && wi < p.W && ch_ok;
+          xc[e] = v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, pok[e]);
+        }
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq)
+        for (int e = 0; e < 4; ++e) {
+          const int qq = e >> 1, pw = e & 1;
+          float z[8], gp[8], acc[8];
+          prep(xc[e], pok[e], z, gp);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[qq][j] = 0.f;
+          for (int j = 0; j < 8; ++j) acc[j] = 0.f;
           // hi even: kh = 1 -> ho = qh.   hi odd: kh = 2 -> ho = qh, kh = 0 -> ho = qh + 1.   wi likewise.
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
@@ -429,34 +446,17 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
               const int kw = pw == 0 ? 1 : (c2 == 0 ? 2 : 0);
               float wv[8];
               lds_f8(wl + (kh * 3 + kw) * DWF_CC + cl * 8, wv);
+              if (!(p.dbg & 2)) {
 #pragma unroll
-              for (int qq = 0; qq < 2; ++qq)
+                for (int j = 0; j < 8; ++j) acc[j] += d[a][qq + c2][j] * wv[j];
+              }
+              if (!(p.dbg & 1)) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[qq][j] += d[a][qq + c2][j] * wv[j];
+                for (int j = 0; j < 8; ++j) dwa[kh * 3 + kw][j] += d[a][qq + c2][j] * z[j];
+              }
             }
           }
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            const int hi = hi0 + 2 * qr + ph, wi = wi0 + 2 * (2 * qc + qq) + pw;
-            emit(acc[qq], v8_load_clamped<T>(xr, ((size_t)(b * p.H + hi) * p.W + wi) * p.C + ch, hi < p.H && wi < p.W && ch_ok), b, hi, wi);
-          }
-        }
-      // dW: owned outputs (qr, 2qc + qq): dW[kh][kw] += dy[ho][wo] * z[2ho - 1 + kh][2wo - 1 + kw] -> z tile (2*qr + kh, 2*wo_l + kw)
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const T* rowp = zt + ((2 * qr + kh) * TL::IW + 4 * qc) * PITCH + cl * 8;
-#pragma unroll
-        for (int cix = 0; cix < 5; ++cix) {
-          float f[8];
-          v8_unpack(v8_load<T>(rowp + cix * PITCH), f);
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            const int kw = cix - 2 * qq;
-            if (kw >= 0 && kw < 3) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) dwa[kh * 3 + kw][j] += f[j] * d[0][qq][j];
-            }
-          }
+          emit(acc, gp, xc[e], pok[e], b, hi, wi0 + 2 * (2 * qc + qq) + pw);
         }
       }
     }
@@ -493,7 +493,7 @@ template <typename T, int S> static size_t dwf_fwd_smem() {
 }
 template <typename T, int S> static size_t dwf_bwd_smem() {
   using TL = DwfTile<S>;
-  return (size_t)(TL::IH * TL::IW + TL::DH * TL::DW) * dwf_pitch<T>() * sizeof(T) + 27 * DWF_CC * sizeof(float);
+  return (size_t)(TL::DH * TL::DW) * dwf_pitch<T>() * sizeof(T) + 27 * DWF_CC * sizeof(float);
 }
 
 template <typename K> static int dwf_launch(K kern, size_t smem, dim3 grid, hipStream_t st, const DwfParams& p, bool* attr_set) {

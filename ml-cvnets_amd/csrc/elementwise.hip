@@ -727,7 +727,17 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_
                                unsigned int stream_id) {
   const unsigned long long seed = *seedp;
   const float inv_keep = 1.0f / (1.0f - p);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+  const DropKey k = drop_key(seed, stream_id, p);
+  const size_t n8 = n / 8;  // 16 B per lane per step; the (rare) tail below goes element by element
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float f[8];
+    v8_unpack(v8_load<T>(x + i * 8), f);
+    dropout_scale8(k, i * 8, inv_keep, f);
+    V8<T> o;
+    v8_pack(f, o);
+    v8_store<T>(y + i * 8, o);
+  }
+  for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     y[i] = from_f<T>(to_f<T>(x[i]) * dropout_scale(seed, stream_id, i, p, inv_keep));
 }
 
@@ -1120,7 +1130,7 @@ extern "C" int cvh_pool_bwd(int dtype, const void* dy, void* dx, int B, int HW, 
 }
 extern "C" int cvh_dropout(int dtype, const void* x, void* y, long long n, float p, const unsigned long long* seed, unsigned int stream_id,
                            void* stream) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (size_t)n, p, seed, stream_id);)
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(((size_t)n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (size_t)n, p, seed, stream_id);)
   CVH_CHECK_LAUNCH();
   return 0;
 }

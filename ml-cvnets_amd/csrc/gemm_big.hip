@@ -124,8 +124,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
 
   // ---- epilogue: accumulators (+bias) -> per-wave LDS staging -> coalesced rows with the fused ops ----
   bf16_t* stg = reinterpret_cast<bf16_t*>(smem) + wave * (64 * STG_PITCH);
-  unsigned long long seed = 0;
-  if (p.drop_p > 0.f) seed = *p.seed;
+  DropKey dkey = {0u, 0u};
+  if (p.drop_p > 0.f) dkey = drop_key(*p.seed, p.stream_id, p.drop_p);
   const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
 #pragma unroll
@@ -169,10 +169,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
         v8_unpack(agr[pass], a);
         act_grad8_mul(v, a, p.actgrad_act);
       }
-      if (p.drop_p > 0.f) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= dropout_scale(seed, p.stream_id, o + j, p.drop_p, inv_keep);
-      }
+      if (p.drop_p > 0.f) dropout_scale8(dkey, o, inv_keep, v);
       if (p.residual) {
         float rr[8];
         v8_unpack(rsr[pass], rr);

@@ -131,6 +131,140 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Grouped variant for C <= 512 (every LayerNorm of MobileViT / MobileViTv2-block tokens, C = 96 ... 480): a row is owned by a group of
+// G = 16 / 32 / 64 lanes, each lane holding 8 consecutive channels (one 16-byte load), so a wave works on 64 / G rows at once and keeps
+// U = 4 such row sets in flight before the first reduction.  The one-row-per-wave kernels above move 8 B per lane with ~half the lanes
+// idle at C = 144 and have ONE 288-byte row per wave in flight: ~9 KB per CU, i.e. latency-bound at 2.1 - 2.7 TB/s.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void ln_fwd_g_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, size_t rows, int C,
+                                                       float eps) {
+  constexpr int RPW = 64 / G, U = 4;          // rows per wave per step, steps in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane % G, gr = lane / G;
+  const int c0 = gl * 8;
+  const bool cok = c0 < C;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { gm[j] = cok ? gamma[c0 + j] : 0.f; bt[j] = cok ? beta[c0 + j] : 0.f; }
+  const float invC = 1.0f / (float)C;
+  const size_t stride = (size_t)gridDim.x * 4 * RPW * U;
+  for (size_t base = ((size_t)blockIdx.x * 4 + wave) * RPW * U; base < rows; base += stride) {
+    V8<T> raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t row = base + u * RPW + gr;
+      raw[u] = v8_load_clamped<T>(x, row * C + c0, cok && row < rows);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t row = base + u * RPW + gr;
+      const bool ok = cok && row < rows;
+      float v[8];
+      v8_unpack(v8_mask(raw[u], ok), v);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+      const float mu = group_sum<G>(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; q += d * d; }
+      if (!cok) q = 0.f;  // idle lanes hold zeros, not (0 - mu)
+      const float rstd = 1.0f / sqrtf(group_sum<G>(q) * invC + eps);
+      if (ok) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * rstd * gm[j] + bt[j];
+        V8<T> ov;
+        v8_pack(o, ov);
+        v8_store<T>(y + row * C + c0, ov);
+        if (gl == 0 && mean_out) { mean_out[row] = mu; rstd_out[row] = rstd; }
+      }
+    }
+  }
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                                       float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C) {
+  constexpr int RPW = 64 / G, U = 2;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C], zeroed, LDS atomics from every (wave, row group)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane % G, gr = lane / G;
+  const int c0 = gl * 8;
+  const bool cok = c0 < C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  float gm[8], dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { gm[j] = cok ? gamma[c0 + j] : 0.f; dg[j] = 0.f; db[j] = 0.f; }
+  const float invC = 1.0f / (float)C;
+  const size_t stride = (size_t)gridDim.x * 4 * RPW * U;
+  for (size_t base = ((size_t)blockIdx.x * 4 + wave) * RPW * U; base < rows; base += stride) {
+    V8<T> rx[U], rd[U];
+    float mu[U], rs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t row = base + u * RPW + gr;
+      const bool ok = cok && row < rows;
+      rx[u] = v8_load_clamped<T>(x, row * C + c0, ok);
+      rd[u] = v8_load_clamped<T>(dy, row * C + c0, ok);
+      const size_t rr = row < rows ? row : 0;
+      mu[u] = mean[rr];
+      rs[u] = rstd[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t row = base + u * RPW + gr;
+      const bool ok = cok && row < rows;
+      float xv[8], dv[8], xh[8], g[8];
+      v8_unpack(v8_mask(rx[u], ok), xv);
+      v8_unpack(v8_mask(rd[u], ok), dv);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[j] = ok ? (xv[j] - mu[u]) * rs[u] : 0.f;
+        g[j] = dv[j] * gm[j];
+        s1 += g[j];
+        s2 += g[j] * xh[j];
+        dg[j] += dv[j] * xh[j];
+        db[j] += dv[j];
+      }
+      const float m1 = group_sum<G>(s1) * invC, m2 = group_sum<G>(s2) * invC;
+      if (ok) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs[u] * (g[j] - m1 - xh[j] * m2);
+        V8<T> ov;
+        v8_pack(o, ov);
+        v8_store<T>(dx + row * C + c0, ov);
+      }
+    }
+  }
+  __syncthreads();
+  if (cok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&red[c0 + j], dg[j]);
+      atomicAdd(&red[C + c0 + j], db[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) part[(size_t)blockIdx.x * 2 * C + i] = red[i];
+}
+
+static inline int ln_group(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
+static inline bool ln_grouped_ok(int C) { return C % 8 == 0 && C <= 512 && cvh_tune_get(CVH_TUNE_LN_PER_ROW) == 0; }  // CVH_TUNE key 8 = 1: the one-row-per-wave kernels
+
 extern "C" int cvh_ln_bwd_rows(long long rows) {
   long long g = (rows + 15) / 16;
   const int cap = cvh_tune_get(CVH_TUNE_COLRED_ROWS);  // workgroups = partial rows of the dgamma / dbeta reduction
@@ -146,6 +280,18 @@ extern "C" int cvh_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   if (g > 8192) g = 8192;
   if (g < 1) g = 1;
   hipStream_t st = (hipStream_t)stream;
+  if (ln_grouped_ok(C) && rows > 0) {
+    const int G = ln_group(C);
+    long long gg = (rows + 4 * (64 / G) * 4 - 1) / (4 * (64 / G) * 4);  // 4 waves x (64 / G) rows x 4 steps per workgroup pass
+    if (gg > 2048) gg = 2048;
+#define LN_FWD_G(TT, GG) hipLaunchKernelGGL((ln_fwd_g_kernel<TT, GG>), dim3((int)gg), dim3(256), 0, st, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, (size_t)rows, C, eps)
+    if (dtype == CVH_DT_BF16) { if (G == 16) LN_FWD_G(bf16_t, 16); else if (G == 32) LN_FWD_G(bf16_t, 32); else LN_FWD_G(bf16_t, 64); }
+    else if (dtype == CVH_DT_F32) { if (G == 16) LN_FWD_G(float, 16); else if (G == 32) LN_FWD_G(float, 32); else LN_FWD_G(float, 64); }
+    else return -1;
+#undef LN_FWD_G
+    CVH_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, (size_t)rows, C, eps);
   else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3((int)g), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, (size_t)rows, C, eps);
   else return -1;
@@ -158,6 +304,17 @@ extern "C" int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const
   int g = cvh_ln_bwd_rows(rows);
   size_t smem = (size_t)4 * 2 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  if (ln_grouped_ok(C) && rows > 0) {  // same partial-row contract: part[g][2][C]
+    const int G = ln_group(C);
+    const size_t sm = (size_t)2 * C * sizeof(float);
+#define LN_BWD_G(TT, GG) hipLaunchKernelGGL((ln_bwd_g_kernel<TT, GG>), dim3(g), dim3(256), sm, st, (const TT*)x, (const TT*)dy, gamma, mean, rstd, (TT*)dx, part, (size_t)rows, C)
+    if (dtype == CVH_DT_BF16) { if (G == 16) LN_BWD_G(bf16_t, 16); else if (G == 32) LN_BWD_G(bf16_t, 32); else LN_BWD_G(bf16_t, 64); }
+    else if (dtype == CVH_DT_F32) { if (G == 16) LN_BWD_G(float, 16); else if (G == 32) LN_BWD_G(float, 32); else LN_BWD_G(float, 64); }
+    else return -1;
+#undef LN_BWD_G
+    CVH_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, (size_t)rows, C);
   else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, (size_t)rows, C);
   else return -1;

@@ -58,3 +58,7 @@ bool gemm_tn_big_eligible(const GemmTNParams& p);
 int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st);
 bool gemm_big_eligible(const ConvGemmParams& p);
 int launch_gemm_big(const ConvGemmParams& p, hipStream_t st);
+
+// gemm_stream.hip
+bool gemm_stream_eligible(const ConvGemmParams& p);
+int launch_gemm_stream(const ConvGemmParams& p, hipStream_t st);

@@ -26,6 +26,8 @@ extern "C" int cvh_pw_gemm_bn(int dtype, const void* a, const cvh_operand_xf* a_
   // mode 2 (two-source operand) is not instantiated for GEMMs: the only BatchNorm-input-gradient consumer on the path is linear and
   // takes the algebraic route of bnlink.hip (measured: the two-source kernels ran at 1.3-2.2 TB/s, the plain ones at 3.5-4.8)
   if (p.a_xf.mode == 2) return -2;
+  if (dtype == CVH_DT_BF16 && gemm_stream_fx_eligible(p))   // plain operand + statistics / BatchNorm-backward epilogue: the 16-wave streaming kernel
+    return launch_gemm_stream_fx(p, cvh_conv_gemm_grid_rows((int)M, N), st);
   if (dtype == CVH_DT_BF16) {
     const bool wp = p.Ktot <= (bk64 ? 64 : 32) && !cvh_tune_get(CVH_TUNE_NO_WAVE_PRIVATE);  // single K step: barrier-free wave-private staging
     if (wp) return bk64 ? dispatch_conv_gemm_nf<bf16_t, 64, 1, 1>(p, nf, st) : dispatch_conv_gemm_nf<bf16_t, 32, 1, 1>(p, nf, st);

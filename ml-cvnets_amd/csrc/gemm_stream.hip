@@ -32,11 +32,15 @@ struct GemmStreamGeom {
   int m_tiles;  // 16-row tiles
   int gx;       // workgroups along M
   int magic;    // ceil(2^16 / (bn / 8)): piece index -> row by multiply + shift (exact for the < 512 pieces of a tile)
+  int rows;     // EM > 0: rows of the partial-statistics buffer the caller allocated (cvh_conv_gemm_grid_rows); rows >= gx are zero-filled
 };
 
 #define GS_NPMAX 8  // row-piece passes of the epilogue: 16 rows x bn / 8 pieces / 64 lanes, bn <= 256
 
-template <int FW, int NKMAX>
+// EM (epilogue mode, the BatchNorm links of bnlink.hpp): 0 plain; 1 + column statistics (sum, sumsq) of the stored values -> partial rows;
+// 2 BatchNorm-backward epilogue: out = acc * act'(scale * aux + shift), statistics (sum g, sum g * xhat), xhat = invstd * aux - mean * invstd.
+// EM > 0 needs bn / 8 to divide 64: a lane then owns the SAME 8 columns in every pass of every tile and its statistics stay in registers.
+template <int FW, int NKMAX, int EM = 0>
 __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmParams p, GemmStreamGeom g) {
   constexpr int CW = 16 * FW;           // chunk width
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -44,7 +48,9 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
   const int SP = g.bn + 8;              // staging pitch (elements): rows stay 16-byte aligned
   bf16_t* Ws = reinterpret_cast<bf16_t*>(smem_raw);                       // [bn][PK]
   float* bias_s = reinterpret_cast<float*>(Ws + (size_t)g.bn * PK);       // [bn]
-  bf16_t* stg_all = reinterpret_cast<bf16_t*>(bias_s + g.bn);             // [waves][16][SP]
+  float* red = bias_s + g.bn;                                             // EM > 0: [2][bn] column sums; EM == 2: + est[4][bn]
+  float* est = red + 2 * g.bn;
+  bf16_t* stg_all = reinterpret_cast<bf16_t*>(bias_s + g.bn + (EM ? 2 * g.bn : 0) + (EM == 2 ? 4 * g.bn : 0));  // [waves][16][SP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   bf16_t* stg = stg_all + wave * (GS_MT * SP);
@@ -67,6 +73,20 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
       v8_store<bf16_t>(Ws + r * PK + kc, v);
     }
     for (int i = tid; i < g.bn; i += 64 * GS_WAVES) bias_s[i] = (p.bias != nullptr && n0 + i < N) ? p.bias[n0 + i] : 0.f;
+    if (EM) {
+      for (int i = tid; i < 2 * g.bn; i += 64 * GS_WAVES) red[i] = 0.f;
+    }
+    if (EM == 2) {  // (invstd, -mean * invstd, scale, shift) of the BatchNorm being back-propagated through
+      for (int i = tid; i < g.bn; i += 64 * GS_WAVES) {
+        const int n = n0 + i;
+        const bool ok = n < N;
+        const float mu = ok ? p.e_stats[n] : 0.f, is = ok ? p.e_stats[N + n] : 0.f;
+        est[i] = is;
+        est[g.bn + i] = -mu * is;
+        est[2 * g.bn + i] = ok ? p.e_stats[2 * N + n] : 0.f;
+        est[3 * g.bn + i] = ok ? p.e_stats[3 * N + n] : 0.f;
+      }
+    }
   }
   __syncthreads();  // the only workgroup barrier
 
@@ -79,12 +99,20 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
   // piece index -> (row, piece in row) by a multiply-shift with a host-side constant: no run-time division, no per-pass registers.
   const int ppr = g.bn / 8, npieces = GS_MT * ppr;
 
+  // EM: this lane's 8 columns (the same in every pass) and their running statistics
+  float cs1[EM ? 8 : 1], cs2[EM ? 8 : 1];
+  const int my_ch = lane % ppr;
+  if (EM) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs1[j] = cs2[j] = 0.f;
+  }
+
   const int l15 = lane & 15, l4 = lane >> 4;
   // fragment loads of 16 rows: lane (l15, l4) reads 16 bytes of row m0 + l15 at column 32 ks + 8 l4; chunks at or beyond K meet zero weights and
   // read column 0 instead (a valid address holding finite data)
   // DB (K <= 192): two operand register sets — the next 16 rows are requested BEFORE this tile's MFMAs and have the whole tile to arrive;
   // otherwise one set, re-requested as soon as the last MFMA pass has consumed it (they then fly under the epilogue only).
-  constexpr bool DB = NKMAX <= 6;
+  constexpr bool DB = NKMAX <= 2 || (NKMAX <= 6 && EM == 0);  // the statistics epilogues need the registers themselves
   bf16x8_t a0[NKMAX], a1[DB ? NKMAX : 1];
   auto load_a = [&](bf16x8_t* a, int tile) __attribute__((always_inline)) {
     int row = tile * GS_MT + l15;
@@ -135,7 +163,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
     }
     wave_lds_sync();
     // ---- epilogue of the 16 x bn tile: 16-byte pieces with the fused tail ----
-#pragma unroll 2
+#pragma unroll(EM ? 1 : 2)
     for (int pass = 0; pass < npass; ++pass) {
       const int idx = lane + 64 * pass;
       const int row = (idx * g.magic) >> 16, ch = idx - row * ppr;
@@ -147,6 +175,26 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
         float v[8];
         v8_unpack(pv, v);
         if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
+        float xh[EM == 2 ? 8 : 1];
+        if (EM == 2) {
+          // the four per-channel vectors come from LDS where they are used (in registers they would cost 32 VGPRs of the 128)
+          float ax[8], yh[8], ka[8], kb[8];
+          v8_unpack(v8_load<bf16_t>(reinterpret_cast<const bf16_t*>(p.e_aux) + o), ax);
+          const float* ev = est + ch * 8;
+          *reinterpret_cast<float4*>(ka) = *reinterpret_cast<const float4*>(ev + 2 * g.bn);
+          *reinterpret_cast<float4*>(ka + 4) = *reinterpret_cast<const float4*>(ev + 2 * g.bn + 4);
+          *reinterpret_cast<float4*>(kb) = *reinterpret_cast<const float4*>(ev + 3 * g.bn);
+          *reinterpret_cast<float4*>(kb + 4) = *reinterpret_cast<const float4*>(ev + 3 * g.bn + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) yh[j] = ax[j] * ka[j] + kb[j];
+          act_grad8_mul(v, yh, p.e_act);
+          *reinterpret_cast<float4*>(ka) = *reinterpret_cast<const float4*>(ev);
+          *reinterpret_cast<float4*>(ka + 4) = *reinterpret_cast<const float4*>(ev + 4);
+          *reinterpret_cast<float4*>(kb) = *reinterpret_cast<const float4*>(ev + g.bn);
+          *reinterpret_cast<float4*>(kb + 4) = *reinterpret_cast<const float4*>(ev + g.bn + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xh[j] = ax[j] * ka[j] + kb[j];
+        }
         if (p.actgrad_aux) {
           float ax[8];
           v8_unpack(v8_load<bf16_t>(reinterpret_cast<const bf16_t*>(p.actgrad_aux) + o), ax);
@@ -162,6 +210,12 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
         V8<bf16_t> ov;
         v8_pack(v, ov);
         v8_store<bf16_t>(out + o, ov);
+        if (EM) {
+          float vr[8];
+          v8_unpack(ov, vr);  // statistics of the values as stored
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { cs1[j] += vr[j]; cs2[j] += vr[j] * (EM == 2 ? xh[j] : vr[j]); }
+        }
       }
     }
     wave_lds_sync();  // staging consumed before the next tile overwrites it
@@ -175,24 +229,41 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
       do_tile(a1, a0);
     }
   }
+  if (EM) {  // workgroup totals -> partial row xb of this column tile; the caller's surplus rows are zeroed
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&red[my_ch * 8 + j], cs1[j]);
+      atomicAdd(&red[g.bn + my_ch * 8 + j], cs2[j]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * g.bn; i += 64 * GS_WAVES) {
+      const int which = i / g.bn, n = n0 + (i - which * g.bn);
+      if (n < N) {
+        p.stats_part[((size_t)xb * 2 + which) * N + n] = red[i];
+        for (int r = g.gx + xb; r < g.rows; r += g.gx) p.stats_part[((size_t)r * 2 + which) * N + n] = 0.f;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-static bool gemm_stream_geom(const ConvGemmParams& p, GemmStreamGeom& g, int& fw, size_t& smem) {
+static bool gemm_stream_geom(const ConvGemmParams& p, int em, GemmStreamGeom& g, int& fw, size_t& smem) {
   const int K = p.Ktot, N = p.N;
-  fw = (N % 48) == 0 ? 3 : ((N % 32) == 0 ? 2 : 0);
+  // em > 0: power-of-two column tiles of 32-column chunks (bn / 8 must divide 64); else exact 48-column chunks where N allows
+  fw = em ? ((N % 32) == 0 ? 2 : 0) : ((N % 48) == 0 ? 3 : ((N % 32) == 0 ? 2 : 0));
   if (fw == 0) return false;
   const int cw = 16 * fw;
   g.Kp = (K + 31) / 32 * 32;
   const int pk = g.Kp + 8;
+  auto bytes = [&](int bn) { return (size_t)bn * pk * 2 + (size_t)bn * 4 * (1 + (em ? 2 : 0) + (em == 2 ? 4 : 0)) + (size_t)GS_WAVES * GS_MT * (bn + 8) * 2; };
   // widest column tile (a multiple of the chunk width that divides N) whose weights + staging fit the 160 KB of a CU
   int best = 0;
   for (int bn = cw; bn <= N && bn <= 256; bn += cw) {
     if (N % bn) continue;
-    const size_t need = (size_t)bn * pk * 2 + (size_t)bn * 4 + (size_t)GS_WAVES * GS_MT * (bn + 8) * 2;
-    if (need <= 156 * 1024) best = bn;
+    if (em && (bn & (bn - 1))) continue;
+    if (bytes(bn) <= 156 * 1024) best = bn;
   }
   if (best == 0) return false;
   g.bn = best;
@@ -205,7 +276,8 @@ static bool gemm_stream_geom(const ConvGemmParams& p, GemmStreamGeom& g, int& fw
   if (gx > need_x) gx = need_x;
   g.gx = gx;
   g.magic = (65536 + best / 8 - 1) / (best / 8);
-  smem = (size_t)best * pk * 2 + (size_t)best * 4 + (size_t)GS_WAVES * GS_MT * (best + 8) * 2;
+  g.rows = 0;
+  smem = bytes(best);
   return true;
 }
 
@@ -217,11 +289,11 @@ bool gemm_stream_eligible(const ConvGemmParams& p) {
   GemmStreamGeom g;
   int fw;
   size_t smem;
-  return gemm_stream_geom(p, g, fw, smem);
+  return gemm_stream_geom(p, 0, g, fw, smem);
 }
 
-template <int FW, int NKMAX> static int launch_gs(const ConvGemmParams& p, const GemmStreamGeom& g, size_t smem, hipStream_t st) {
-  auto kern = gemm_stream_kernel<FW, NKMAX>;
+template <int FW, int NKMAX, int EM> static int launch_gs(const ConvGemmParams& p, const GemmStreamGeom& g, size_t smem, hipStream_t st) {
+  auto kern = gemm_stream_kernel<FW, NKMAX, EM>;
   static size_t attr = 0;  // one instantiation = one static
   if (smem > 64 * 1024 && smem > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -237,8 +309,38 @@ int launch_gemm_stream(const ConvGemmParams& p, hipStream_t st) {
   GemmStreamGeom g;
   int fw;
   size_t smem;
-  if (!gemm_stream_geom(p, g, fw, smem)) return -2;
+  if (!gemm_stream_geom(p, 0, g, fw, smem)) return -2;
   const bool small_k = g.Kp <= 192;  // operand registers: 4 per 32-wide K step (24 / 40 of the 128-register budget)
-  if (fw == 3) return small_k ? launch_gs<3, 6>(p, g, smem, st) : launch_gs<3, 10>(p, g, smem, st);
-  return small_k ? launch_gs<2, 6>(p, g, smem, st) : launch_gs<2, 10>(p, g, smem, st);
+  if (fw == 3) return small_k ? launch_gs<3, 6, 0>(p, g, smem, st) : launch_gs<3, 10, 0>(p, g, smem, st);
+  return small_k ? launch_gs<2, 6, 0>(p, g, smem, st) : launch_gs<2, 10, 0>(p, g, smem, st);
+}
+
+// BatchNorm-link GEMMs with a PLAIN A operand (cvh_pw_gemm_bn, gemm_fx.hip): forward expansion convs (statistics epilogue) and the
+// projection dX with the BatchNorm-backward epilogue.  `rows` = rows of the caller's partial-statistics buffer.
+static int gs_em(const ConvGemmParams& p) { return p.e_mode == 1 ? 2 : (p.stats_part != nullptr ? 1 : 0); }
+bool gemm_stream_fx_eligible(const ConvGemmParams& p) {
+  if (cvh_tune_get(CVH_TUNE_NO_STREAM_GEMM)) return false;
+  if (p.a_xf.mode != 0 || p.sc_s != 0 || p.Ktot > 192 || (p.Ktot % 8) != 0 || p.M < 32768) return false;
+  if (p.e_mode == 1 && p.stats_part == nullptr) return false;
+  const int em = gs_em(p);
+  if (em == 0) return false;
+  if (em == 2 && p.Ktot > 64) return false;  // the BatchNorm-backward epilogue next to 6 K steps of operand registers does not fit 128 VGPRs
+  GemmStreamGeom g;
+  int fw;
+  size_t smem;
+  return gemm_stream_geom(p, em, g, fw, smem);
+}
+int launch_gemm_stream_fx(const ConvGemmParams& p, int rows, hipStream_t st) {
+  GemmStreamGeom g;
+  int fw;
+  size_t smem;
+  const int em = gs_em(p);
+  if (!gemm_stream_geom(p, em, g, fw, smem) || fw != 2) return -2;
+  if (rows < g.gx) {  // never more workgroup rows than the caller allocated
+    g.gx = rows;
+  }
+  g.rows = rows;
+  const bool tiny_k = g.Kp <= 64;
+  if (em == 1) return tiny_k ? launch_gs<2, 2, 1>(p, g, smem, st) : launch_gs<2, 6, 1>(p, g, smem, st);
+  return tiny_k ? launch_gs<2, 2, 2>(p, g, smem, st) : -2;
 }

@@ -94,3 +94,70 @@ def test_stream_gemm_fused_epilogues(M, K, N):
     finally:
         _lib.call("cvh_set_tuning", KEY_NO_STREAM, 0)
     assert float(((y == res) != (y_old == res)).float().mean()) < 1e-4   # same elements dropped (dropped => out == residual)
+
+
+@pytest.mark.parametrize("M,K,N", [(65536, 16, 64), (40000, 32, 128), (50000, 64, 256), (33000, 96, 384), (32768, 128, 512)])
+def test_stream_gemm_statistics_epilogue(M, K, N):
+    """cvh_pw_gemm_bn, plain operand + column statistics of the stored values (forward link of a BatchNorm behind the conv)"""
+    from cvnets_amd import _lib, ops
+    from cvnets_amd.fused import _pw_gemm
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = torch.randn(N, K, device=DEV, generator=g) * K ** -0.5
+    wp = ops.pack_weight(w.view(N, K, 1, 1), torch.bfloat16, 0)
+    outs = []
+    for off in (0, 1):
+        _lib.call("cvh_set_tuning", KEY_NO_STREAM, off)
+        try:
+            y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            part, R = _pw_gemm(x, None, K, wp, y, M, N, want_stats=True)
+            torch.cuda.synchronize()
+            outs.append((y, part.view(R, 2, N).sum(0)))
+        finally:
+            _lib.call("cvh_set_tuning", KEY_NO_STREAM, 0)
+    (y, st), (y_old, st_old) = outs
+    ref = x.float() @ w.bfloat16().float().t()
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 8e-3
+    yf = y.float().double()
+    assert torch.allclose(st[0].double(), yf.sum(0), rtol=1e-4, atol=1e-3 * float(yf.abs().sum(0).max()))   # statistics OF THE STORED values
+    assert torch.allclose(st[1].double(), (yf * yf).sum(0), rtol=1e-4)
+    assert torch.allclose(st, st_old, rtol=2e-3, atol=2e-3 * float(st_old.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,N", [(65536, 32, 64), (40000, 64, 128), (50000, 64, 256)])
+def test_stream_gemm_bn_backward_epilogue(M, K, N):
+    """projection dX of the fused InvertedResidual: g = (dy W) * act'(scale * y + shift), statistics (sum g, sum g * xhat)"""
+    from cvnets_amd import _lib, ops
+    from cvnets_amd.fused import _pw_gemm
+    g_ = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn(M, K, device=DEV, generator=g_).bfloat16()
+    w = torch.randn(N, K, device=DEV, generator=g_) * K ** -0.5
+    wp = ops.pack_weight(w.view(N, K, 1, 1), torch.bfloat16, 0)
+    yraw = (torch.randn(M, N, device=DEV, generator=g_) * 1.5 + 0.3).bfloat16()
+    mean, var = yraw.float().mean(0), yraw.float().var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    gamma, beta = torch.rand(N, device=DEV, generator=g_) + 0.5, torch.randn(N, device=DEV, generator=g_) * 0.2
+    stats = torch.stack([mean, invstd, gamma * invstd, beta - mean * gamma * invstd]).contiguous()
+    for act in (1, 0):
+        outs = []
+        for off in (0, 1):
+            _lib.call("cvh_set_tuning", KEY_NO_STREAM, off)
+            try:
+                out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+                part, R = _pw_gemm(dy, None, K, wp, out, M, N, e_mode=1, e_aux=yraw, e_stats=stats, e_act=act, want_stats=True)
+                torch.cuda.synchronize()
+                outs.append((out, part.view(R, 2, N).sum(0)))
+            finally:
+                _lib.call("cvh_set_tuning", KEY_NO_STREAM, 0)
+        (o, st), (o_old, st_old) = outs
+        z = (yraw.float() * stats[2] + stats[3]).requires_grad_(True)
+        fz = torch.nn.functional.silu(z) if act == 1 else z
+        (gz,) = torch.autograd.grad(fz.sum(), z)
+        ref = (dy.float() @ w.bfloat16().float().t()) * gz
+        assert float((o.float() - ref).abs().max() / ref.abs().max()) < 1e-2, act
+        of = o.float().double()
+        xhat = ((yraw.float() - mean) * invstd).double()
+        assert torch.allclose(st[0].double(), of.sum(0), rtol=1e-3, atol=1e-3 * float(of.abs().sum(0).max()))
+        assert torch.allclose(st[1].double(), (of * xhat).sum(0), rtol=1e-3, atol=1e-3 * float((of * xhat).abs().sum(0).max()))
+        assert float((o.float() - o_old.float()).abs().max()) <= 2 ** -6 * float(ref.abs().max())
+        assert torch.allclose(st, st_old, rtol=5e-3, atol=5e-3 * float(st_old.abs().max()))

@@ -244,7 +244,19 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
   } else if (!accumulate || skinny_shape || p.bias_part != nullptr) {
     return -2;
   }
-  const bool skinny = skinny_shape && !fx && dtype == CVH_DT_BF16 && KH * KW == 1 && p.stride == 1 && p.pad == 0 && C2 == 0;
+  // plain operands, or a plain dY with act(c0 * x + c1) on X (the projection dW of the fused InvertedResidual blocks)
+  const bool fx_ok = !fx || (p.dy_xf.mode == 0 && p.x_xf.mode == 1 && p.bias_part == nullptr);
+  const bool skinny = skinny_shape && fx_ok && dtype == CVH_DT_BF16 && KH * KW == 1 && p.stride == 1 && p.pad == 0 && C2 == 0;
+  if (skinny && fx) {
+    const int nt = (N + 31) / 32, kt = (p.Ktot + 31) / 32;
+    const dim3 g(splits), b(256);
+#define SKINNY_XF(NT_, KT_, PF_) \
+  if (nt == NT_ && kt == KT_) hipLaunchKernelGGL((gemm_tn_skinny_kernel<NT_, KT_, PF_, 0, 1>), g, b, 0, st, p);
+    SKINNY_XF(1, 1, 4) SKINNY_XF(2, 1, 4) SKINNY_XF(3, 1, 3) SKINNY_XF(4, 1, 3) SKINNY_XF(1, 2, 3) SKINNY_XF(2, 2, 3)
+#undef SKINNY_XF
+    CVH_CHECK_LAUNCH();
+    return gemm_dw_finish(p, rows, N, KH, KW, C1, C2, Cin_real, dw, accumulate, st);
+  }
   if (skinny) {
     const int nt = (N + 31) / 32, kt = (p.Ktot + 31) / 32;
     const dim3 g(splits), b(256);

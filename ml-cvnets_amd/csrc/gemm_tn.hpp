@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNParams p) {
 // stage, PF stages in flight per wave.  Every wave writes its own partial tile (rows of the scratch = 4 x splits); with BIAS the
 // column sums of dY (the bias gradient of the same layer) ride along.
 // =============================================================================================
-template <int NT, int KT, int PF, int BIAS>
+// XF = 1: the X operand is act(c0 * x + c1) (x_xf mode 1, bnlink.hpp) — the projection dW of the fused InvertedResidual, whose X is the raw
+// depthwise output: the transform is applied to the registers on their way into LDS (a lane's 8 columns are fixed: coefficients in registers).
+template <int NT, int KT, int PF, int BIAS, int XF = 0>
 __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(GemmTNParams p) {
   using T = bf16_t;
   constexpr int PITCH = 36;
@@ -298,6 +300,11 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(GemmTNParams p) {
     }
   };
 
+  Coef8 kx[XF ? KT : 1];
+  if (XF) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) coef8_load(kx[t], p.x_xf, t * 32 + cq * 8, t * 32 + cq * 8 < K);
+  }
   const int ms_w = m_begin + wave * 32;
   // no control flow inside the ring (see gemm_tn_kernel): stages past m_end are fully predicated off and add nothing
 #pragma unroll
@@ -325,7 +332,11 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(GemmTNParams p) {
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
           const bool ok = t * 32 + cq * 8 < K;
-          store_transposed_pair(Xt + (t * 32 + cq * 8) * PITCH + 2 * mp, PITCH, v8_mask(rx[u][t][0], va && ok), v8_mask(rx[u][t][1], vb && ok));
+          if (XF)
+            store_transposed_pair(Xt + (t * 32 + cq * 8) * PITCH + 2 * mp, PITCH, xf_apply<T>(rx[u][t][0], rx[u][t][0], kx[t], 1, p.x_xf.act, va && ok),
+                                  xf_apply<T>(rx[u][t][1], rx[u][t][1], kx[t], 1, p.x_xf.act, vb && ok));
+          else
+            store_transposed_pair(Xt + (t * 32 + cq * 8) * PITCH + 2 * mp, PITCH, v8_mask(rx[u][t][0], va && ok), v8_mask(rx[u][t][1], vb && ok));
         }
         wave_lds_sync();
         load_stage(rd[u], rx[u], ms + PF * STEP);

@@ -318,6 +318,10 @@ int cvh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
                       long long rows, int C, float eps, void* stream);
 int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                       float* part, long long rows, int C, void* stream);
+/* the same with dx += dres: the gradient arriving over the residual branch that forks off in front of the LayerNorm (x -> LN(x) and
+ * x -> ... + x, cvnets/modules/transformer.py:139-155) joins inside this kernel instead of in a separate elementwise add */
+int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                          float* part, long long rows, int C, const void* dres, void* stream);
 int cvh_ln_bwd_rows(long long rows); /* rows of part[rows][2][C] (dgamma | dbeta) */
 
 /* ---- fused multi-head self-attention ------------------------------------------------------------ */

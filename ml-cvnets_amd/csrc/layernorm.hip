@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C) {
+                                                     float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C, const T* __restrict__ dres) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C / 4;
@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - m1 - xh[it][e] * m2);
+        if (dres != nullptr) {
+          float rv[4];
+          v4_unpack(v4_load<T>(dres + row * C + ch * 4), rv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rv[e];
+        }
         V4<T> ov;
         v4_pack(o, ov);
         v4_store<T>(dx + row * C + ch * 4, ov);
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(256) void ln_fwd_g_kernel(const T* __restrict__ x, 
 template <typename T, int G>
 __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                                       float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C) {
+                                                       float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C,
+                                                       const T* __restrict__ dres /* optional: dx += dres (residual fork) */) {
   constexpr int RPW = 64 / G, U = 2;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C], zeroed, LDS atomics from every (wave, row group)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, 
   const float invC = 1.0f / (float)C;
   const size_t stride = (size_t)gridDim.x * 4 * RPW * U;
   for (size_t base = ((size_t)blockIdx.x * 4 + wave) * RPW * U; base < rows; base += stride) {
-    V8<T> rx[U], rd[U];
+    V8<T> rx[U], rd[U], rr[U];
     float mu[U], rs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, 
       const bool ok = cok && row < rows;
       rx[u] = v8_load_clamped<T>(x, row * C + c0, ok);
       rd[u] = v8_load_clamped<T>(dy, row * C + c0, ok);
+      rr[u] = v8_load_clamped<T>(dres != nullptr ? dres : dy, row * C + c0, ok);
       const size_t rr = row < rows ? row : 0;
       mu[u] = mean[rr];
       rs[u] = rstd[rr];
@@ -244,6 +252,12 @@ __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, 
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rs[u] * (g[j] - m1 - xh[j] * m2);
+        if (dres != nullptr) {
+          float rv[8];
+          v8_unpack(rr[u], rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += rv[j];
+        }
         V8<T> ov;
         v8_pack(o, ov);
         v8_store<T>(dx + row * C + c0, ov);
@@ -298,8 +312,14 @@ extern "C" int cvh_layernorm_fwd(int dtype, const void* x, const float* gamma, c
   CVH_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                     float* part, long long rows, int C, const void* dres, void* stream);
 extern "C" int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                                  float* part, long long rows, int C, void* stream) {
+  return cvh_layernorm_bwd_res(dtype, x, dy, gamma, mean, rstd, dx, part, rows, C, nullptr, stream);
+}
+extern "C" int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                     float* part, long long rows, int C, const void* dres, void* stream) {
   if (C % 4 || C > 64 * 4 * LN_MAXIT || C <= 0) return -2;
   int g = cvh_ln_bwd_rows(rows);
   size_t smem = (size_t)4 * 2 * C * sizeof(float);
@@ -307,7 +327,7 @@ extern "C" int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const
   if (ln_grouped_ok(C) && rows > 0) {  // same partial-row contract: part[g][2][C]
     const int G = ln_group(C);
     const size_t sm = (size_t)2 * C * sizeof(float);
-#define LN_BWD_G(TT, GG) hipLaunchKernelGGL((ln_bwd_g_kernel<TT, GG>), dim3(g), dim3(256), sm, st, (const TT*)x, (const TT*)dy, gamma, mean, rstd, (TT*)dx, part, (size_t)rows, C)
+#define LN_BWD_G(TT, GG) hipLaunchKernelGGL((ln_bwd_g_kernel<TT, GG>), dim3(g), dim3(256), sm, st, (const TT*)x, (const TT*)dy, gamma, mean, rstd, (TT*)dx, part, (size_t)rows, C, (const TT*)dres)
     if (dtype == CVH_DT_BF16) { if (G == 16) LN_BWD_G(bf16_t, 16); else if (G == 32) LN_BWD_G(bf16_t, 32); else LN_BWD_G(bf16_t, 64); }
     else if (dtype == CVH_DT_F32) { if (G == 16) LN_BWD_G(float, 16); else if (G == 32) LN_BWD_G(float, 32); else LN_BWD_G(float, 64); }
     else return -1;
@@ -315,8 +335,8 @@ extern "C" int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const
     CVH_CHECK_LAUNCH();
     return 0;
   }
-  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, (size_t)rows, C);
-  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, (size_t)rows, C);
+  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, (size_t)rows, C, (const bf16_t*)dres);
+  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, (size_t)rows, C, (const float*)dres);
   else return -1;
   CVH_CHECK_LAUNCH();
   return 0;

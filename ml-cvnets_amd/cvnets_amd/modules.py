@@ -172,11 +172,12 @@ class TransformerEncoder(nn.Module):
             y = ops.layer_norm_tokens(x, ln2, seqmap)
             h = ops.linear(ops.linear(y, fc1.weight, fc1.bias, act=act_code(act)), fc2.weight, fc2.bias, drop_p=p2)
             return ops.drop_path(h, x, sd, True, seqmap)
-        # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue
-        y = ops.layer_norm_tokens(x, ln1, seqmap)
+        # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue; the fork x -> (x, LN(x)) is one autograd
+        # node, so the two gradients of x meet inside the LayerNorm backward kernel
+        x, y = ops.layer_norm_fork(x, ln1, seqmap)
         x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x)
         # x = x + Dropout(W2 act(W1 LN(x)))
-        y = ops.layer_norm_tokens(x, ln2, seqmap)
+        x, y = ops.layer_norm_fork(x, ln2, seqmap)
         a = act_code(act)
         if not _FUSED_FFN_BWD or fc1.out_features >= 1024:
             # transformer-sized FFNs (ViT-B: 3072 hidden): measured -4.5 % with the fusion — the erf/exp epilogue serialises behind

@@ -953,6 +953,60 @@ def layer_norm(x2d, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x2d, gamma, beta, float(eps))
 
 
+_LN_FORK = os.environ.get("CVH_LN_FORK", "1") != "0"
+
+
+class LayerNormForkFn(torch.autograd.Function):
+    """x -> (x, LayerNorm(x)) as ONE autograd node: the pre-norm residual fork of TransformerEncoder (cvnets/modules/transformer.py:139-155,
+    `res = x; x = norm(x); ...; x = x + res`).  With two separate consumers of x autograd sums their gradients in an elementwise add
+    kernel (one read of each + one write per fork, 18 forks per MobileViT-S step); here the gradient of the pass-through output joins
+    inside the LayerNorm backward kernel (cvh_layernorm_bwd_res)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _check_dev(x)
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        mr = _f32(2, x.device, rows)
+        _lib.call("cvh_layernorm_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mr[0]), _p(mr[1]), rows, C, float(eps), _stream())
+        ctx.beta = beta
+        ctx.save_for_backward(x, gamma, mr)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dout):
+        x, gamma, mr = ctx.saved_tensors
+        rows, C = x.shape
+        if dout is None:  # only the pass-through was used
+            return dres, None, None, None
+        dout = dout.contiguous()
+        if dres is not None:
+            dres = dres.contiguous()
+            if dres.dtype != x.dtype:
+                dres = dres.to(x.dtype)
+        R = _lib.query("cvh_ln_bwd_rows", rows)
+        part = _f32(R * 2 * C, x.device)
+        dx = torch.empty_like(x)
+        _lib.call("cvh_layernorm_bwd_res", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _p(dres), _stream())
+        sg, sb = _grad_sink(gamma), _grad_sink(ctx.beta)
+        if sg is not None and sb is not None:
+            if not (defer_reduce(part, sg, R, 2 * C, C) and defer_reduce(part, sb, R, 2 * C, C, part_offset=C)):
+                _lib.call("cvh_sum_partials", _p(part), R, 2 * C, C, _p(sg), 1.0, 1, _stream())
+                _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, R, 2 * C, C, _p(sb), 1.0, 1, _stream())
+            return dx, None, None, None
+        dgb = _f32(2 * C, x.device)
+        _lib.call("cvh_sum_partials", _p(part), R, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())
+        return dx, dgb[:C], dgb[C:], None
+
+
+def layer_norm_fork(x2d, ln, seqmap):
+    """returns (x, LayerNorm(x)); falls back to two consumers of x where the fused node does not apply (the reference's S == C quirk branch)"""
+    S, C = seqmap[1], x2d.shape[1]
+    if (S == C and getattr(ln, "reference_quirk", True)) or not torch.is_grad_enabled() or not x2d.requires_grad or not _LN_FORK:
+        return x2d, layer_norm_tokens(x2d, ln, seqmap)
+    return LayerNormForkFn.apply(x2d, ln.weight, ln.bias, float(ln.eps))
+
+
 # ------------------------------------------------------------------------------------------------
 # fused multi-head self-attention on the qkv token matrix
 # ------------------------------------------------------------------------------------------------

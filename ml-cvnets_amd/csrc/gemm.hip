@@ -220,7 +220,8 @@ extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
 // 1 when cvh_gemm_dw_bias can emit the column sums of dY from the dW kernel it would pick (everything but the transformer-sized
 // direct-to-LDS kernel of gemm_big.hip, whose operands never pass through registers)
 extern "C" int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot) {
-  if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot)) return 0;
+  // the direct-to-LDS kernel folds it only through a padded column of ones: needs K % 128 != 0 (gemm_big.hip)
+  if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot)) return (Ktot % 128) != 0 ? 1 : 0;
   return M > 0 ? 1 : 0;
 }
 
@@ -280,7 +281,7 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 1>), grid, dim3(256), 0, st, p);
     else return -1;
   } else if (dtype == CVH_DT_BF16 && p.part != nullptr && gemm_tn_big_eligible(p)) {  // transformer-sized linears (ViT-B / CLIP)
-    if (p.bias_part != nullptr) return -2;  // cvh_gemm_dw_folds_bias() says so
+    if (p.bias_part != nullptr && (p.Ktot % 128) == 0) return -2;  // cvh_gemm_dw_folds_bias() says so
     const int rc = launch_gemm_tn_big(p, splits, st);
     if (rc) return rc;
   } else if (dtype == CVH_DT_BF16) {

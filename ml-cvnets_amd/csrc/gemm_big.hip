@@ -24,6 +24,9 @@ constexpr int STG_PITCH = 64 + 8;            // bf16 elements per staged output 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];  // zero-initialised: source of out-of-range rows / chunks
+#define ONE8 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80
+__device__ __attribute__((aligned(128))) unsigned short g_ones_line[64] = {ONE8, ONE8, ONE8, ONE8, ONE8, ONE8, ONE8, ONE8};  // bf16 1.0
+#undef ONE8
 
 __device__ __forceinline__ void glds16(const bf16_t* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
@@ -271,16 +274,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
   const bf16_t* gy = dy + (size_t)(m_begin + row_off) * N + n0 + (lane & 3) * 8;
   const bf16_t* gx = x + (size_t)(m_begin + row_off) * K + k0 + (lane & 3) * 8;
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_line);
+  // Bias gradient for free: with K % 128 != 0 the last k tile carries zero-padded columns anyway; feeding the FIRST padded 8-column chunk
+  // (columns K .. K+7) from a line of ones makes output column K the column sums of dY over this split — sum_m dY[m][n] * 1 — which is the
+  // bias gradient of the same layer (otherwise a separate pass over dY, cvh_colsum).  bf16 1.0 x dY is exact, accumulation is the MFMA's fp32.
+  const bool fold_bias = RAGGED && p.bias_part != nullptr;
+  const bf16_t* ones = reinterpret_cast<const bf16_t*>(g_ones_line);
   auto issue = [&](int step, int buf) {
     const bool ok = m_begin + step * 64 + row_off < m_end;
     unsigned char* y_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024;
     unsigned char* x_dst = y_dst + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      const int kcol = k0 + j * 32 + (lane & 3) * 8;
       const bool oky = ok && (!RAGGED || n0 + j * 32 + (lane & 3) * 8 < N);
-      const bool okx = ok && (!RAGGED || k0 + j * 32 + (lane & 3) * 8 < K);
+      const bool okx = ok && (!RAGGED || kcol < K);
       glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
-      glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : zero, x_dst + j * 1024);
+      glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : ((fold_bias && ok && kcol == K) ? ones : zero), x_dst + j * 1024);
     }
   };
 
@@ -322,7 +331,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
 #pragma unroll
     for (int fk = 0; fk < 2; ++fk) {
       const int k = k0 + wave_k * 64 + fk * 32 + (lane & 31);
-      if (RAGGED && k >= K) continue;
+      if (RAGGED && k >= K) {
+        if (fold_bias && k == K) {  // the ones column: bias_part[split][n]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
+            if (n < N) p.bias_part[(size_t)by * N + n] = acc[fn][fk][r];
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);

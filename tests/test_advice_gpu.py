@@ -76,3 +76,26 @@ def test_failed_backward_does_not_poison_the_next_one():
     finally:
         ops.set_inplace_param_grads(False)
         cvnets_amd.set_compute_dtype(None)
+
+
+@pytest.mark.parametrize("M,N,K", [(70000, 288, 144), (40001, 144, 288), (33000, 432, 144), (20000, 192, 192), (9000, 96, 64)])
+def test_dw_kernel_emits_bias_gradient_through_ones_column(M, N, K):
+    """gemm_tn128_kernel: the first zero-padded column of the last k tile is fed with ones, so output column K = column sums of dY = the bias
+    gradient of the same layer (LinearLayer backward, cvnets/layers/linear_layer.py:74-91) — checked against a plain sum and the dW itself."""
+    from cvnets_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M)
+    dy = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    assert _lib.query("cvh_gemm_dw_folds_bias", 1, M, N, K) == 1
+    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, N, K)
+    rows = n_scr // (N * K)
+    scr = torch.empty(n_scr, device="cuda")
+    bpart = torch.full((rows, N), float("nan"), device="cuda")
+    dw = torch.empty(N, K, device="cuda")
+    _lib.call("cvh_gemm_dw_bias", 1, dy.data_ptr(), x.data_ptr(), None, K, 0, dw.data_ptr(), bpart.data_ptr(), M, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, K,
+              scr.data_ptr(), n_scr, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want_b = dy.float().double().sum(0)
+    assert torch.allclose(bpart.double().sum(0), want_b, rtol=1e-5, atol=1e-4 * float(want_b.abs().max()))
+    want_w = dy.float().double().t() @ x.float().double()
+    assert float((dw.double() - want_w).norm() / want_w.norm()) < 1e-5

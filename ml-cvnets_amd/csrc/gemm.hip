@@ -82,6 +82,7 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   p.sc_s = 0; p.sc_KW = p.sc_C = p.sc_H = p.sc_W = p.sc_Ho = p.sc_Wo = 0;
   if (p.M <= 0 || N <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16 && conv3x3_eligible(p)) return launch_conv3x3(p, cvh_conv_gemm_grid_rows(p.M, N), st);  // MobileViT-block 3x3 convs
   if (dtype == CVH_DT_BF16 && gemm_stream_eligible(p)) return launch_gemm_stream(p, st);  // short-K token linears / 1x1 convs (MobileViT blocks)
   if (dtype == CVH_DT_BF16 && gemm_big_eligible(p)) return launch_gemm_big(p, st);  // transformer-sized linears (ViT-B / CLIP)
   const int nf = choose_nf(N);

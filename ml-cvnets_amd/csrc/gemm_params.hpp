@@ -62,5 +62,8 @@ int launch_gemm_big(const ConvGemmParams& p, hipStream_t st);
 // gemm_stream.hip
 bool gemm_stream_eligible(const ConvGemmParams& p);
 int launch_gemm_stream(const ConvGemmParams& p, hipStream_t st);
+// conv3x3.hip
+bool conv3x3_eligible(const ConvGemmParams& p);
+int launch_conv3x3(const ConvGemmParams& p, int rows, hipStream_t st);
 bool gemm_stream_fx_eligible(const ConvGemmParams& p);
 int launch_gemm_stream_fx(const ConvGemmParams& p, int rows, hipStream_t st);

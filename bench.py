@@ -95,75 +95,120 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------------------
-# dominant kernel (by total time in the committed rocprofv3 CSV): the dW GEMM gemm_tn_kernel<bf16_t, 0, 0>
+# dominant kernel family
 # ------------------------------------------------------------------------------------------------
-class _DwShapeLog:
-    """records every (M, N, K, conv geometry) the backward pass hands to cvh_gemm_dw during one eager step"""
+# WHICH family dominates, its in-step average launch duration and its HBM traffic come from profiles/step_profile.json — written by
+# tools/make_step_profile.py from rocprofv3 runs (kernel trace + two PMC passes) of THIS command, stamped with a hash of the sources it was
+# measured on; a profile of another source tree is refused (the line then says so and carries the live measurements only).
+# Live, on every run: the family's launches per step and their algorithmic bytes (tallied by the library itself during one eager step), and an
+# isolated re-timing of exactly those launches with HIP events on the launch stream.
+def _src_hash():
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(REPO, "ml-cvnets_amd", "csrc", "*")) + glob.glob(os.path.join(REPO, "ml-cvnets_amd", "cvnets_amd", "*.py")) +
+                   [os.path.join(REPO, "bench.py"), os.path.join(REPO, "include", "cvnets_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+FAMILIES = {  # kernel families the library tallies (cvh_stream_counters): name in the rocprofv3 kernel table -> (index, description)
+    "gemm_stream_kernel": (0, "gemm_stream_kernel<FW, NK, EM> (csrc/gemm_stream.hip): every short-K pointwise GEMM of the step — token linears, 1x1 "
+                              "convolutions, BatchNorm-link expansion / projection GEMMs"),
+    "conv_gemm_kernel": (1, "conv_gemm_kernel<T, NF, BK, FX, WP> (csrc/conv_gemm.hpp): the implicit-GEMM family — conv_1, operand-transform (BatchNorm-link) "
+                            "projections, two-source expansion dX, K > 320 linears, classifier"),
+}
+
+
+class _StreamGemmLog:
+    """records the (M, K, N, epilogue operands) of every launch that lands on gemm_stream_kernel during one eager step, by watching the
+    library's own tally (cvh_stream_counters) around the two entry points that can dispatch to it"""
 
     def __init__(self):
-        self.shapes = []
+        self.calls = []
+        self.launches = 0
+        self.alg_bytes = 0
+        self.tallies = [0, 0, 0, 0]
 
     def __enter__(self):
-        from cvnets_amd import ops
-        self._ops, self._orig = ops, ops._weight_grad
+        import ctypes
+        from cvnets_amd import _lib
+        self._lib = _lib
+        self._orig = _lib.call
+        buf = (ctypes.c_longlong * 4)()
+        self._buf = buf
 
-        def logged(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, **kw):
-            self.shapes.append((B, H, W, Ho, Wo, C1, C2, KH, KW, stride, pad, dil, N, Cin_real))
-            return self._orig(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, **kw)
+        def tally():
+            _lib.load().cvh_stream_counters(0, buf)
+            return buf[0], buf[1]
 
-        ops._weight_grad = logged
-        from cvnets_amd import fused
-        fused.DW_SHAPE_LOG = self.shapes  # the Gram / g^T x GEMMs of the fused InvertedResidual blocks
+        _lib.load().cvh_stream_counters(1, None)
+        self._tally = tally
+
+        def call(name, *a):
+            if name not in ("cvh_conv_gemm", "cvh_pw_gemm_bn"):
+                return self._orig(name, *a)
+            n0, _ = tally()
+            rc = self._orig(name, *a)
+            n1, _ = tally()
+            if n1 > n0:
+                if name == "cvh_conv_gemm":  # (dtype, src1, src2, C1, C2, wgt, out, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, bias, act, save_pre, aux, aact, res, p, seed, sid, stats, st)
+                    self.calls.append(("g", a[7] * a[10] * a[11], a[3], a[17], dict(bias=a[18] is not None, act=a[19], save_pre=a[20] is not None,
+                                                                                actgrad=a[21] is not None, aact=a[22], residual=a[23] is not None, drop=a[24])))
+                else:  # (dtype, a, a_xf, K, wgt, out, M, N, residual, e_mode, e_aux, e_stats, e_act, stats_part, st)
+                    self.calls.append(("f", a[6], a[3], a[7], dict(residual=a[8] is not None, e_mode=a[9], e_act=a[12], stats=a[13] is not None)))
+            return rc
+
+        _lib.call = call  # ops.py / fused.py call through the module attribute, so this patches them too
         return self
 
-    def __exit__(self, *a):
-        from cvnets_amd import fused
-        fused.DW_SHAPE_LOG = None
-        self._ops._weight_grad = self._orig
+    def __exit__(self, *exc):
+        self._lib.call = self._orig
+        self.launches, self.alg_bytes = self._tally()
+        self.tallies = list(self._buf)
 
 
-def dominant_kernel_probe(dtype, shapes):
-    """Times the step's dominant kernel class live with HIP events on the launch stream: every dW GEMM (cvh_gemm_dw ->
-    gemm_tn_kernel + split reduction) of one training step, on synthetic operands of the recorded shapes, back to back.
-    Algorithmic bytes per launch = M*(N + K)*sizeof(T): dY and the (implicit) im2col input are each read once; dW is negligible."""
+def stream_gemm_probe(log):
+    """isolated re-timing of the step's gemm_stream_kernel launches (synthetic operands of the recorded shapes, same epilogues), HIP events on
+    the launch stream; returns (total ms per step's worth of launches, launches)"""
     from cvnets_amd import _lib, ops
+    from cvnets_amd.fused import _pw_gemm
     dev = torch.device("cuda")
     st = torch.cuda.current_stream()
-    esz = 2 if dtype == torch.bfloat16 else 4
-    total_ms, total_bytes, n = 0.0, 0, 0
-    worst = None
-    for (B, H, W, Ho, Wo, C1, C2, KH, KW, stride, pad, dil, N, Cin_real) in shapes:
-        M, Ktot = B * Ho * Wo, KH * KW * (C1 + C2)
-        dy = torch.randn(M, N, device=dev).to(dtype)
-        x = torch.randn(B * H * W, C1, device=dev).to(dtype)
-        x2 = torch.randn(B * H * W, C2, device=dev).to(dtype) if C2 else None
-        dw = torch.empty(N * Cin_real * KH * KW, device=dev)
-        n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, N, Ktot)
-        scr = torch.empty(max(n_scr, 1), device=dev)
+    total_ms, n = 0.0, 0
+    seed = torch.tensor([12345], dtype=torch.int64, device=dev)
+    for kind, M, K, N, o in log.calls:
+        x = torch.randn(M, K, device=dev).bfloat16()
+        wp = ops.pack_weight(torch.randn(N, K, 1, 1, device=dev) * 0.05, torch.bfloat16, 0)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        aux = torch.randn(M, N, device=dev).bfloat16() if (o.get("actgrad") or o.get("residual") or o.get("e_mode")) else None
+        pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if o.get("save_pre") else None
+        if kind == "g":
+            bias = torch.zeros(N, device=dev) if o["bias"] else None
 
-        def run():
-            _lib.call("cvh_gemm_dw", 1 if dtype == torch.bfloat16 else 0, dy.data_ptr(), x.data_ptr(), None if x2 is None else x2.data_ptr(), C1, C2,
-                      dw.data_ptr(), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, scr.data_ptr(), n_scr, 0, st.cuda_stream)
+            def run():
+                ops._conv_gemm(x, None, K, 0, wp, out, M, 1, 1, 1, 1, 1, 1, 1, 0, 1, N, bias=bias, act=o["act"], save_pre=pre,
+                               actgrad_aux=aux if o["actgrad"] else None, actgrad_act=o["aact"], residual=aux if o["residual"] else None,
+                               drop_p=o["drop"], seed=seed if o["drop"] > 0 else None, stream_id=1)
+        else:
+            stats = (torch.rand(4, N, device=dev) + 0.5) if o["e_mode"] else None
+
+            def run():
+                _pw_gemm(x, None, K, wp, out, M, N, residual=aux if o["residual"] else None, e_mode=o["e_mode"], e_aux=aux if o["e_mode"] else None,
+                         e_stats=stats, e_act=o["e_act"], want_stats=o["stats"])
         run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 3
         e0.record(st)
-        for _ in range(reps):
+        for _ in range(3):
             run()
         e1.record(st)
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        nbytes = M * (N + (C1 + C2)) * esz  # the KH*KW taps re-read the same input rows (L2): count the tensor once
-        total_ms += ms
-        total_bytes += nbytes
+        total_ms += e0.elapsed_time(e1) / 3
         n += 1
-        if worst is None or ms > worst[0]:
-            worst = (ms, f"M={M} N={N} K={Ktot}")
-        del dy, x, x2, dw, scr
-    return {"kernel": "gemm_tn_kernel<bf16_t, *, 0> / gemm_tn_skinny_kernel / gemm_tn128_kernel (+ split reduction): every plain dW GEMM dY^T x im2col(X) of one training step",
-            "launches_per_step": n, "avg_ms": round(total_ms / max(n, 1), 4), "total_ms_per_step": round(total_ms, 3),
-            "algorithmic_bytes": int(total_bytes / max(n, 1)), "achieved_GBps": round(total_bytes / (total_ms * 1e-3) / 1e9, 1),
-            "longest_launch": {"ms": round(worst[0], 4), "shape": worst[1]} if worst else None}
+        del x, wp, out, aux, pre
+    return total_ms, n
 
 
 # ------------------------------------------------------------------------------------------------
@@ -269,7 +314,7 @@ def run(args):
     # eager warm-up (also creates every lazily-built tensor before capture); the first step logs the dW GEMM shapes for the kernel probe
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    dw_log = _DwShapeLog()
+    dw_log = _StreamGemmLog()
     with torch.cuda.stream(side):
         for it in range(2):
             zero_grads()
@@ -345,24 +390,55 @@ def run(args):
         if graph_err:
             out["config"]["hipgraph_error"] = graph_err
         roofline = out["roofline"]
-        pmc = None
-        try:  # HBM traffic cannot be counted from inside the process: it comes from the committed rocprofv3 PMC passes of this command
-            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-            if args.batch == pmc["step"]["images"] and headline:
-                roofline["traffic"] = pmc["step"]["total_bytes"] / pmc["step"]["images"]  # bytes per image, like algorithmic_bytes_per_image
-                roofline["traffic_source"] = pmc["source"]
+        prof, stale = None, None
+        try:  # HBM traffic and the in-step kernel table cannot be produced from inside the process: they come from the rocprofv3 runs of this command
+            prof = json.load(open(os.path.join(REPO, "profiles", "step_profile.json")))
+            stale = prof.get("src_hash") != _src_hash()
+            if args.batch != prof["step"]["images"] or not headline:
+                prof = None
         except Exception:
-            pmc = None
+            prof = None
+        if prof is not None and not stale:
+            roofline["traffic"] = prof["step"]["total_bytes"] / prof["step"]["images"]  # bytes per image, like algorithmic_bytes_per_image
+            roofline["traffic_source"] = prof["source"]
+        elif prof is not None:
+            roofline["traffic_note"] = "profiles/step_profile.json was measured on a different source tree (src_hash mismatch): not quoted"
+        # the dominant family = the one with the largest share of kernel time in the rocprofv3 table of THIS source tree (without a valid
+        # profile: the streaming GEMM, which the live probe below re-times)
+        dom = prof["dominant"] if (prof is not None and not stale and prof["dominant"] in FAMILIES) else "gemm_stream_kernel"
+        fi, fdesc = FAMILIES[dom]
+        n_l, n_b = dw_log.tallies[2 * fi], dw_log.tallies[2 * fi + 1]
+        dk = {"kernel": fdesc, "family": dom, "launches_per_step": int(n_l), "algorithmic_bytes": int(n_b / max(n_l, 1)),
+              "algorithmic_bytes_note": "per launch, averaged over the step's launches: input tensor(s) + out + every [M][N] epilogue operand, tallied by the "
+                                        "library during one eager step (cvh_stream_counters)"}
+        if prof is not None and not stale:
+            fam = {f["family"]: f for f in prof["families"]}
+            f = fam.get(dom)
+            if f is not None:
+                dk.update({"share_of_kernel_time": f["share_of_kernel_time"], "avg_ms": f["avg_ms"], "ms_per_step": f["ms_per_step"],
+                           "profile_launches_per_step": f["launches_per_step"], "traffic": f["hbm_bytes_per_step"] / max(f["launches_per_step"], 1),
+                           "avg_ms_source": "in-step average from the rocprofv3 kernel trace of this command (profiles/step_profile.json)"})
+                dk["achieved_GBps"] = round(n_b / max(n_l, 1) / (f["avg_ms"] * 1e-3) / 1e9, 1)
+                dk["frac"] = round(dk["achieved_GBps"] * 1e9 / HBM_PEAK, 4)
+            if prof["dominant"] not in FAMILIES:
+                d0 = fam[prof["dominant"]]
+                dk["note"] = f"the profile's largest family is {prof['dominant']} ({d0['share_of_kernel_time']:.3f} of kernel time, {d0['hbm_GBps']} GB/s of counter traffic): not tallied"
+            dk["runner_up"] = {k: {"share_of_kernel_time": fam[k]["share_of_kernel_time"], "avg_ms": fam[k]["avg_ms"], "hbm_GBps": fam[k]["hbm_GBps"]}
+                               for k in list(fam)[:4] if k != dom}
         if not args.no_kernel_probe:
             try:
-                dk = dominant_kernel_probe(dtype, dw_log.shapes)
-                dk["frac"] = round(dk["achieved_GBps"] * 1e9 / HBM_PEAK, 4)
-                if pmc is not None and args.batch == pmc["step"]["images"] and "dominant_kernel" in pmc:
-                    dk["traffic"] = pmc["dominant_kernel"].get("bytes_per_launch")
-                    dk["rocprof_avg_ms"] = pmc["dominant_kernel"].get("rocprof_avg_ms")
-                roofline["dominant_kernel"] = dk
+                iso_ms, n_iso = stream_gemm_probe(dw_log)
+                iso = {"kernel": "gemm_stream_kernel", "launches": n_iso, "total_ms_per_step": round(iso_ms, 3), "avg_ms": round(iso_ms / max(n_iso, 1), 5),
+                       "achieved_GBps": round(dw_log.alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
+                       "what": "the step's gemm_stream_kernel launches re-issued back to back on synthetic operands, HIP events on the launch stream"}
+                dk["isolated_probe"] = iso
+                dk["isolated_avg_ms"], dk["isolated_achieved_GBps"] = iso["avg_ms"], iso["achieved_GBps"]
+                if "avg_ms" not in dk:  # no valid profile: the live numbers are all there is
+                    dk.update({"avg_ms": dk["isolated_avg_ms"], "avg_ms_source": "isolated HIP-event probe (no valid profiles/step_profile.json for this source tree)",
+                               "achieved_GBps": dk["isolated_achieved_GBps"], "frac": round(dk["isolated_achieved_GBps"] * 1e9 / HBM_PEAK, 4)})
             except Exception as e:  # pragma: no cover
-                roofline["dominant_kernel"] = {"error": str(e)[:200]}
+                dk["probe_error"] = str(e)[:200]
+        roofline["dominant_kernel"] = dk
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

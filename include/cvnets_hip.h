@@ -69,6 +69,10 @@ int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2,
                   const void* residual, float drop_p, const unsigned long long* seed, unsigned int stream_id,
                   float* stats_part, void* stream);
 int cvh_conv_gemm_grid_rows(int M, int N);
+/* measurement aid (bench.py): launches since the last reset and the sum of their algorithmic bytes (input tensor(s) + output + every [M][N]
+ * epilogue operand) of the two GEMM kernel families: out[0..1] = gemm_stream_kernel, out[2..3] = conv_gemm_kernel; out = long long[4];
+ * reset != 0 clears the tallies */
+int cvh_stream_counters(int reset, long long* out);
 /* dW[N][Cin_real][KH][KW] (float32, torch layout) = (accumulate ? dW : 0) + dY[M][N]^T x im2col(src)[M][K].  The M range is split
  * over workgroups; with `scratch` (>= cvh_gemm_dw_scratch_elems(M, N, K) floats) every split stores its partial tile and a second
  * kernel sums them (no atomics); with scratch == NULL the splits add into dW with fp32 atomics (accumulate must be 1 and dW zeroed /

@@ -384,10 +384,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 // =============================================================================================
 // host-side dispatch
 // =============================================================================================
+// host-side tally of the conv_gemm_kernel family (bench.py, cvh_stream_counters): launches and their algorithmic bytes — the input tensor(s),
+// the output and every [M][N] epilogue operand once, 2 (bf16) / 4 (f32) bytes per element; defined in gemm.hip
+extern long long g_cg_launches, g_cg_bytes;
+
 template <typename T, int NF, int BK, int FX, int WP = 0>
 static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   constexpr int BM = 128, BN = 32 * NF;
   ConvGemmParams p = p0;
+  {
+    const int extra = (p.save_pre != nullptr) + (p.actgrad_aux != nullptr) + (p.residual != nullptr) + (FX == 1 && p.e_mode == 1 ? 1 : 0);
+    const long long in_rows = (long long)p.B * p.H * p.W;
+    g_cg_launches += 1;
+    g_cg_bytes += (in_rows * (p.C1 + p.C2) + (long long)p.M * p.N * (1 + extra)) * (long long)sizeof(T);
+  }
   p.m_tiles = (p.M + BM - 1) / BM;
   const int n_tiles = (p.N + BN - 1) / BN;
   const int cap = cvh_tune_get(CVH_TUNE_GEMM_GRID);

@@ -56,6 +56,21 @@ __global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __rest
   }
 }
 
+long long g_cg_launches = 0, g_cg_bytes = 0;
+void gemm_stream_counters(int reset, long long* out2);  // gemm_stream.hip
+extern "C" int cvh_stream_counters(int reset, long long* out) {
+  if (out != nullptr) {
+    gemm_stream_counters(0, out);
+    out[2] = g_cg_launches;
+    out[3] = g_cg_bytes;
+  }
+  if (reset) {
+    gemm_stream_counters(1, nullptr);
+    g_cg_launches = g_cg_bytes = 0;
+  }
+  return 0;
+}
+
 extern "C" int cvh_conv_gemm_grid_rows(int M, int N) {
   // number of stats-partial rows conv_gemm writes for an (M, N) problem (== gridDim.x)
   (void)N;

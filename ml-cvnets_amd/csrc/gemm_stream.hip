@@ -292,8 +292,21 @@ bool gemm_stream_eligible(const ConvGemmParams& p) {
   return gemm_stream_geom(p, 0, g, fw, smem);
 }
 
+// host-side tally of what went through this kernel family (bench.py: launches per step and their ALGORITHMIC bytes — every operand and
+// result tensor once: A, out, and the epilogue's aux / residual / saved pre-activation where present; weights and statistics neglected)
+static long long g_gs_launches = 0, g_gs_bytes = 0;
+void gemm_stream_counters(int reset, long long* out2) {  // C entry point: cvh_stream_counters (gemm.hip)
+  if (out2 != nullptr) { out2[0] = g_gs_launches; out2[1] = g_gs_bytes; }
+  if (reset) g_gs_launches = g_gs_bytes = 0;
+}
+
 template <int FW, int NKMAX, int EM> static int launch_gs(const ConvGemmParams& p, const GemmStreamGeom& g, size_t smem, hipStream_t st) {
   auto kern = gemm_stream_kernel<FW, NKMAX, EM>;
+  {
+    const int extra = (p.save_pre != nullptr) + (p.actgrad_aux != nullptr) + (p.residual != nullptr) + (EM == 2 ? 1 : 0);
+    g_gs_launches += 1;
+    g_gs_bytes += (long long)p.M * ((long long)p.Ktot + (long long)p.N * (1 + extra)) * 2;
+  }
   static size_t attr = 0;  // one instantiation = one static
   if (smem > 64 * 1024 && smem > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -14,6 +14,7 @@ Tensor conventions
 from __future__ import annotations
 
 import ctypes
+import contextlib
 import os
 
 import itertools
@@ -399,7 +400,10 @@ def _colsum(x2d: torch.Tensor, rows: int, C: int, sink: Optional[torch.Tensor] =
 # does.  With in-place parameter gradients they are launched on a SIDE HIP stream behind an event on the main stream, so the many
 # under-filled dW / reduce launches of the small layers overlap with the dX chain; the main stream re-joins at the end of the
 # backward pass (autograd end-of-backward callback).  Captured into a hipGraph this becomes two parallel branches per layer.
-_ASYNC_PARAM_GRADS = os.environ.get("CVH_ASYNC_DW", "1") != "0"
+# Default OFF since round 3: with the faster dX chain the overlap stopped paying (92.3 ms with, 91.9 ms without, same box), and the fp32
+# MobileViTv2 golden case that failed once in ~25 suite runs in round 2 reproduces ONLY with the side stream on (tools/stress_v2.py: 1 of 300
+# runs at 2e-3 with CVH_ASYNC_DW=1, 0 of 300 with it off — a cross-stream ordering hole that single-stream execution cannot have).
+_ASYNC_PARAM_GRADS = os.environ.get("CVH_ASYNC_DW", "0") == "1"
 _side_streams = {}
 # id of the autograd graph task (one per backward call) whose end-of-backward callback is queued, or None.  Tied to the task id rather
 # than a bare flag: autograd DROPS queued callbacks when a backward raises (an OOM the engine skips, a kernel error), and a stale "already
@@ -515,15 +519,17 @@ def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad
     Ktot = KH * KW * (C1 + C2)
     M = B * Ho * Wo
     n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, N, Ktot)
-    side = _param_grad_stream(dy.device) if sink is not None else None
-    if side is not None:
+    if sink is not None:
+        # in-place parameter gradients: split partials now, their sum at the end of backward (cvh_reduce_multi) — or right here when deferral is
+        # off; on the parameter-gradient side stream when that is enabled (CVH_ASYNC_DW=1), else on the current stream
+        side = _param_grad_stream(dy.device)
         folded = False
-        with torch.cuda.stream(side):
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             scr = _f32(max(n_scr, 1), dy.device)
-            for t in (dy, x, x2):
-                if t is not None:
-                    t.record_stream(side)
-            # split partials now, their sum at the end of backward (cvh_reduce_multi) — or right here when deferral is off
+            if side is not None:
+                for t in (dy, x, x2):
+                    if t is not None:
+                        t.record_stream(side)
             rows = n_scr // (N * Ktot)
             deferred = n_scr > 0 and defer_reduce(scr, sink, rows, N * Ktot, N * Ktot,
                                                   kind=0 if (KH * KW == 1 and Cin_real == Ktot) else 1, N=N, Ktot=Ktot, Cin=C1 + C2,
@@ -535,13 +541,11 @@ def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad
             _lib.call("cvh_gemm_dw_bias", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, None if deferred else _p(sink), _p(bpart) if folded else None,
                       B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real, _p(scr), n_scr, 1, _stream())
         return (None, folded) if bias_sink is not None else None
-    if bias_sink is not None:
-        return _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real), False
-    dw = sink if sink is not None else torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(weight.shape, dtype=torch.float32, device=dy.device)
     scr = _f32(max(n_scr, 1), dy.device)
     _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), _p(x2), C1, C2, _p(dw), B, H, W, Ho, Wo, KH, KW, stride, pad, dil, N, Cin_real,
-              _p(scr), n_scr, 1 if sink is not None else 0, _stream())
-    return None if sink is not None else dw
+              _p(scr), n_scr, 0, _stream())
+    return (dw, False) if bias_sink is not None else dw
 
 
 def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentum, eps):

@@ -28,6 +28,13 @@ ALGO = {"vit_base": (106.25, 190.9, "mfma"), "vit_tiny": (None, None, "mfma"), "
 def build(name, batch, dev):
     import cvnets_amd
 
+    if name.endswith("_ckpt"):  # as shipped: gradient_checkpointing: true (config/classification/imagenet/vit.yaml:81, clip_vit.yaml:94)
+        m, loss_of, desc = build(name[:-5], batch, dev)
+        for mod in m.modules():
+            if hasattr(mod, "gradient_checkpointing"):
+                mod.gradient_checkpointing = True
+        return m, loss_of, desc + ", gradient checkpointing"
+
     def seeded_caption_tokens(batch: int, ctx: int, vocab: int, seed: int) -> torch.Tensor:
         """synthetic captions: ids in [1, vocab-2], one EOT (= vocab-1) at a random position >= 4, padding (0) after it"""
         g = torch.Generator().manual_seed(seed)
@@ -131,7 +138,7 @@ def run(name, batch, steps, warmup, dtype, use_graph):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ips = batch * steps / wall
-    gf, mb, bound = ALGO[name]
+    gf, mb, bound = ALGO[name[:-5] if name.endswith("_ckpt") else name]
     out = {"model": name, "workload": f"{desc}, {batch} img/GPU", "dtype": str(dtype).split(".")[-1], "images_per_sec": round(ips, 1),
            "ms_per_step": round(wall * 1e3 / steps, 3), "gpu_ms_per_step_hip_events": round(e0.elapsed_time(e1) / steps, 3), "hipgraph": graph is not None,
            "loss": round(float(loss), 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "bound": bound}
@@ -235,7 +242,7 @@ if __name__ == "__main__":
                 print(json.dumps({"model": name, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
             continue
         try:
-            print(json.dumps(run(name, int(batches[name]), a.steps, a.warmup, torch.bfloat16 if a.dtype == "bf16" else torch.float32, not a.no_graph)), flush=True)
+            print(json.dumps(run(name, int(batches[name[:-5] if name.endswith("_ckpt") else name]), a.steps, a.warmup, torch.bfloat16 if a.dtype == "bf16" else torch.float32, not a.no_graph)), flush=True)
         except Exception as e:  # keep going: one model failing must not hide the others
             print(json.dumps({"model": name, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
         torch.cuda.empty_cache()

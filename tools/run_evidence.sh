@@ -1,0 +1,17 @@
+# Round evidence in ONE gpurun call: full GPU suite, smoke, the default bench line, rocprofv3 kernel stats + per-step timeline of the bench
+# command, the two PMC traffic passes, profiles/step_profile.json (kernel table + traffic, stamped with the source hash), bench line again
+# (now quoting the fresh profile).      usage: bash tools/run_evidence.sh r03x
+TAG=${1:-r03}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG; O=gpurun_out/$TAG
+(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^  File" | tail -5) > $O/tests_gpu.log; tail -2 $O/tests_gpu.log
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2) > $O/smoke.log; cat $O/smoke.log
+rm -rf $O/prof; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-probe > $O/prof.log 2>&1; tail -1 $O/prof.log | cut -c1-160
+python tools/prof_summary.py $O/prof 60 40 > $O/prof_summary.txt 2>&1; python tools/timeline.py $O/prof > $O/timeline.txt 2>&1; head -3 $O/timeline.txt
+python tools/step_trace.py $O/prof > $O/step_trace.txt 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/pmc_$c; timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-kernel-probe --no-cpu-baseline > $O/pmc_$c.log 2>&1; done
+python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/pmc_summary.txt 2>&1; head -3 $O/pmc_summary.txt
+python tools/make_step_profile.py $O/prof $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE 1024 $TAG > $O/step_profile.json 2>$O/step_profile.err; head -12 $O/step_profile.json
+cp $O/step_profile.json profiles/step_profile.json   # so that the bench line below quotes THIS build's profile (copied back into the repo by hand afterwards)
+(timeout 900 python bench.py 2>&1 | tail -1) > $O/bench.json; cut -c1-600 $O/bench.json
+cp $O/prof/bench_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+find $O -name "*counter_collection.csv" -size +8M -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; du -sh $O

@@ -190,29 +190,51 @@ __device__ __forceinline__ Frag<float> lds_frag_strided(const float* tile, int p
   return f;
 }
 
-// write a 32x32 accumulator tile TRANSPOSED into LDS: acc rows (keys) run along the LDS row of column
-// q = lane&31:  dst[(lane&31)*pitch + row0 + acc_row(r)].  Registers 4i..4i+3 are 4 consecutive rows.
-template <typename T>
-__device__ __forceinline__ void store_acc_transposed(T* dst, int pitch, int row0, const float* v /*16*/, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    V4<T> pk;
-    v4_pack(v + 4 * i, pk);
-    v4_store<T>(dst + (lane & 31) * pitch + row0 + 8 * i + 4 * (lane >> 5), pk);
-  }
+// The same transposed-operand fragment with the contraction index PERMUTED into the order in which a 32x32 accumulator holds its rows:
+// slot j of lane half h <-> tile row k0 + 8*(j>>2) + 4*h + (j&3).  A 32x32 accumulator whose ROWS are the next product's contraction
+// index (P^T, dS^T, P, dS) is then fed to the next MFMA straight from registers (frag_from_acc) — the probabilities never touch LDS.
+__device__ __forceinline__ Frag<bf16_t> lds_frag_strided_perm(const bf16_t* tile, int pitch, int k0, int col0, int lane) {
+  const int i = lane & 15;
+  const bf16_t* p = tile + (k0 + 4 * (lane >> 5) + (i >> 2)) * pitch + col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
+  const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + 8 * pitch));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(bf16x8_t, both);
+  return f;
 }
-// write an accumulator tile in natural orientation: dst[(row0 + acc_row(r))*pitch + col0 + (lane&31)]
-template <typename T>
-__device__ __forceinline__ void store_acc_natural(T* dst, int pitch, int row0, int col0, const float* v, int lane) {
+__device__ __forceinline__ Frag<float> lds_frag_strided_perm(const float* tile, int pitch, int k0, int col0, int lane) {
+  const float* p = tile + (k0 + 4 * (lane >> 5)) * pitch + col0 + (lane & 31);
+  Frag<float> f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dst[(row0 + acc_row(r, lane)) * pitch + col0 + (lane & 31)] = from_f<T>(v[r]);
+  for (int j = 0; j < 8; ++j) f.v[j] = p[((j & 3) + 8 * (j >> 2)) * pitch];
+  return f;
 }
+// registers 8t .. 8t+7 of a 32x32 accumulator as the operand fragment of k-step t (rows 16t .. 16t+15 in the permuted order above)
+template <typename T> __device__ __forceinline__ Frag<T> frag_from_acc(const f32x16_t& acc, int t);
+template <> __device__ __forceinline__ Frag<bf16_t> frag_from_acc<bf16_t>(const f32x16_t& acc, int t) {
+  const uint4 u = make_uint4(f2bf_pk(acc[8 * t + 0], acc[8 * t + 1]), f2bf_pk(acc[8 * t + 2], acc[8 * t + 3]),
+                             f2bf_pk(acc[8 * t + 4], acc[8 * t + 5]), f2bf_pk(acc[8 * t + 6], acc[8 * t + 7]));
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(bf16x8_t, u);
+  return f;
+}
+template <> __device__ __forceinline__ Frag<float> frag_from_acc<float>(const f32x16_t& acc, int t) {
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = acc[8 * t + j];
+  return f;
+}
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
-__device__ __forceinline__ bool key_visible(const AttnParams& p, int s, int key, int q) {
-  if (key >= p.S) return false;
-  if (p.causal && key > q) return false;
-  if (p.kpm && p.kpm[(size_t)s * p.S + key]) return false;
-  return true;
+// Key visibility without per-score branches: every kernel builds, once, a table (LDS) or a per-lane flag of the keys that no query may
+// see (beyond the sequence end, or set in the key padding mask); the causal rule is a compare.  Masked scores become -inf, so exp2 -> 0.
+__device__ __forceinline__ int key_dead_flag(const AttnParams& p, int s, int key) {
+  if (key >= p.S) return 1;
+  return (p.kpm && p.kpm[(size_t)s * p.S + key]) ? 1 : 0;
 }
 
 // =============================================================================================
@@ -228,24 +250,25 @@ static size_t carve_bytes(size_t elems, size_t esz) { return (elems * esz + 15) 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <typename T, int CP, int VEC, int NW>
+// CPK = head width rounded up to the 16-wide MFMA k-step (the contraction length of Q K^T); the LDS tiles and the output fragments are
+// CP = CPK rounded up to 32 columns wide (columns >= c are zero).
+template <typename T, int CPK, int VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
+  constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
-  constexpr int PP = lds_pitch<T>(KB);
   constexpr int NFC = CP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* sp = smem_raw;
   T* Ks = carve<T>(sp, KB * PQ);
   T* Vs = carve<T>(sp, KB * PQ);
   T* Qs_all = carve<T>(sp, NW * 32 * PQ);
-  T* Ps_all = carve<T>(sp, NW * 32 * PP);
   int* rk = carve<int>(sp, p.S);       // row index of every key of this sequence
   int* rq_all = carve<int>(sp, NW * 32);
+  int* kd = carve<int>(sp, (p.S + 63) & ~63);  // 1 = key can never be seen
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* Qs = Qs_all + wave * 32 * PQ;
-  T* Ps = Ps_all + wave * 32 * PP;
   int* rq = rq_all + wave * 32;
   const int nqb = (p.S + 31) / 32;
   const int nqg = (nqb + NW - 1) / NW;
@@ -261,6 +284,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   const int ld = 3 * p.d;
 
   for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
+  for (int i = tid; i < ((p.S + 63) & ~63); i += 64 * NW) kd[i] = key_dead_flag(p, s, i);
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
   TileStager<T, CP, VEC, KB, 64 * NW> kst, vst;
@@ -273,14 +297,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
     TileStager<T, CP, VEC, 32, 64> qst;
     qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
     load_kv(0);  // first K/V tile requested together with Q
-    qst.store(Qs, PQ, p.scaling, lane);
+    qst.store(Qs, PQ, p.scaling * kLog2e, lane);  // scores come out in log2 units: exp(s - m) is one v_exp_f32, no multiply
   }
 
   const int my_q = q0 + (lane & 31);
   const bool drop = p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = -1e30f, l_run = 0.f;  // running max (log2 units) and normaliser
   f32x16_t oacc[NFC];
 #pragma unroll
   for (int f = 0; f < NFC; ++f) oacc[f] = acc_zero();
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int f = 0; f < KB / 32; ++f) sacc[f] = acc_zero();
 #pragma unroll
-    for (int kk = 0; kk < CP; kk += 16) {
+    for (int kk = 0; kk < CPK; kk += 16) {
       Frag<T> bq = lds_frag(Qs, PQ, 0, kk, lane);
 #pragma unroll
       for (int f = 0; f < KB / 32; ++f) {
@@ -307,34 +331,43 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
         mma32(sacc[f], ak, bq);
       }
     }
-    float sv[KB / 32][16];
+    if (!full_tile) {  // one workgroup-uniform branch per tile, selects inside
+#pragma unroll
+      for (int f = 0; f < KB / 32; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key0 = kv0 + f * 32 + 8 * i + 4 * (lane >> 5);
+          const int4 dd = *reinterpret_cast<const int4*>(kd + key0);
+          const int dead[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool hide = dead[e] != 0 || (p.causal && key0 + e > my_q);
+            sacc[f][4 * i + e] = hide ? -INFINITY : sacc[f][4 * i + e];
+          }
+        }
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int f = 0; f < KB / 32; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = sacc[f][r];
-        if (!full_tile) {
-          const int key = kv0 + f * 32 + acc_row(r, lane);
-          if (!key_visible(p, s, key, my_q)) v = -INFINITY;
-        }
-        sv[f][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[f][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = fast_exp(m_run - m_new);
+    const float alpha = exp2_fast(m_run - m_new);
     float rs = 0.f;
 #pragma unroll
-    for (int f = 0; f < KB / 32; ++f) {
+    for (int f = 0; f < KB / 32; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pv = fast_exp(sv[f][r] - m_new);
+        const float pv = exp2_fast(sacc[f][r] - m_new);
         rs += pv;  // the softmax normaliser runs over the undropped probabilities
-        if (drop) pv *= attn_keep(p, seed, inv_keep, s, head, my_q, kv0 + f * 32 + acc_row(r, lane));
-        sv[f][r] = pv;
+        sacc[f][r] = pv;
       }
-      store_acc_transposed<T>(Ps, PP, f * 32, sv[f], lane);
+    if (drop) {
+#pragma unroll
+      for (int f = 0; f < KB / 32; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[f][r] *= attn_keep(p, seed, inv_keep, s, head, my_q, kv0 + f * 32 + acc_row(r, lane));
     }
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
@@ -343,17 +376,19 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
     for (int f = 0; f < NFC; ++f)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[f][r] *= alpha;
-    wave_lds_sync();  // P is wave-private: only this wave reads it back (a workgroup barrier here made every wave wait for the slowest softmax)
-    // O^T[c][q] += sum_key V[key][c] * P^T[key][q]
+    // O^T[c][q] += sum_key V[key][c] * P^T[key][q]: the accumulator rows of P^T (keys) ARE this product's contraction index, so P^T goes
+    // from the accumulator registers straight into the B operand and V is read in the matching key order
 #pragma unroll
-    for (int kk = 0; kk < KB; kk += 16) {
-      Frag<T> bp = lds_frag(Ps, PP, 0, kk, lane);
+    for (int f = 0; f < KB / 32; ++f)
 #pragma unroll
-      for (int f = 0; f < NFC; ++f) {
-        Frag<T> av = lds_frag_strided(Vs, PQ, kk, f * 32, lane);
-        mma32(oacc[f], av, bp);
+      for (int t = 0; t < 2; ++t) {
+        const Frag<T> bp = frag_from_acc<T>(sacc[f], t);
+#pragma unroll
+        for (int fc = 0; fc < NFC; ++fc) {
+          Frag<T> av = lds_frag_strided_perm(Vs, PQ, f * 32 + 16 * t, fc * 32, lane);
+          mma32(oacc[fc], av, bp);
+        }
       }
-    }
   }
 
   if (my_q < p.S) {
@@ -376,7 +411,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
             if (cb + e < p.c) out[row * p.d + head * p.c + cb + e] = from_f<T>(o[e]);
         }
       }
-    if (lane < 32 && p.lse) p.lse[((size_t)s * p.h + head) * p.S + my_q] = m_run + __logf(l_run);
+    if (lane < 32 && p.lse) p.lse[((size_t)s * p.h + head) * p.S + my_q] = (m_run + __log2f(l_run)) * kLn2;
   }
 }
 
@@ -441,11 +476,11 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_rows_kernel(const T* __rest
 // =============================================================================================
 // backward dQ: wave = (sequence, head, 32-query block); the NW waves of a workgroup share the K/V tiles
 // =============================================================================================
-template <typename T, int CP, int VEC, int NW>
+template <typename T, int CPK, int VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
-  constexpr int PP = lds_pitch<T>(KB);
   constexpr int NFC = CP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* sp = smem_raw;
@@ -453,14 +488,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   T* Vs = carve<T>(sp, KB * PQ);
   T* Qs_all = carve<T>(sp, NW * 32 * PQ);
   T* dOs_all = carve<T>(sp, NW * 32 * PQ);
-  T* dSs_all = carve<T>(sp, NW * 32 * PP);
   int* rk = carve<int>(sp, p.S);
   int* rq_all = carve<int>(sp, NW * 32);
+  int* kd = carve<int>(sp, (p.S + 63) & ~63);  // 1 = key can never be seen
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* Qs = Qs_all + wave * 32 * PQ;
   T* dOs = dOs_all + wave * 32 * PQ;
-  T* dSs = dSs_all + wave * 32 * PP;
   int* rq = rq_all + wave * 32;
   const int nqb = (p.S + 31) / 32;
   const int nqg = (nqb + NW - 1) / NW;
@@ -477,6 +511,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   const int ld = 3 * p.d;
 
   for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
+  for (int i = tid; i < ((p.S + 63) & ~63); i += 64 * NW) kd[i] = key_dead_flag(p, s, i);
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
   TileStager<T, CP, VEC, KB, 64 * NW> kst, vst;
@@ -490,14 +525,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
     qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
     dst.load(dout, p.d, head * p.c, rq, 32, p.c, lane);
     load_kv(0);
-    qst.store(Qs, PQ, p.scaling, lane);
+    qst.store(Qs, PQ, p.scaling * kLog2e, lane);  // scores in log2 units
     dst.store(dOs, PQ, 1.0f, lane);
   }
 
   const int my_q = q0 + (lane & 31);
   const bool q_ok = my_q < p.S;
   const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
-  const float lse = p.lse[sidx], dsum = p.dsum[sidx];
+  const float lse = p.lse[sidx] * kLog2e, dsum = p.dsum[sidx];
   const bool drop = p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -519,7 +554,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int f = 0; f < KB / 32; ++f) { sacc[f] = acc_zero(); dpacc[f] = acc_zero(); }
 #pragma unroll
-    for (int kk = 0; kk < CP; kk += 16) {
+    for (int kk = 0; kk < CPK; kk += 16) {
       Frag<T> bq = lds_frag(Qs, PQ, 0, kk, lane);
       Frag<T> bd = lds_frag(dOs, PQ, 0, kk, lane);
 #pragma unroll
@@ -530,33 +565,43 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
         mma32(dpacc[f], av, bd);  // dP^T = V dO^T
       }
     }
+    if (drop) {  // dP = keep * (dO V^T)
 #pragma unroll
-    for (int f = 0; f < KB / 32; ++f) {
-      float ds[16];
+      for (int f = 0; f < KB / 32; ++f)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        bool vis = true;  // (rows of absent queries are computed but never stored)
-        if (!full_tile) {
-          const int key = kv0 + f * 32 + acc_row(r, lane);
-          vis = q_ok && key_visible(p, s, key, my_q);
+        for (int r = 0; r < 16; ++r) dpacc[f][r] *= attn_keep(p, seed, inv_keep, s, head, my_q, kv0 + f * 32 + acc_row(r, lane));
+    }
+    if (!full_tile) {  // (rows of absent queries are computed but never stored)
+#pragma unroll
+      for (int f = 0; f < KB / 32; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key0 = kv0 + f * 32 + 8 * i + 4 * (lane >> 5);
+          const int4 dd = *reinterpret_cast<const int4*>(kd + key0);
+          const int dead[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool hide = !q_ok || dead[e] != 0 || (p.causal && key0 + e > my_q);
+            sacc[f][4 * i + e] = hide ? -INFINITY : sacc[f][4 * i + e];  // exp2 -> 0
+          }
         }
-        float dpv = dpacc[f][r];
-        if (drop) dpv *= attn_keep(p, seed, inv_keep, s, head, my_q, kv0 + f * 32 + acc_row(r, lane));  // dP = keep * (dO V^T)
-        ds[r] = vis ? fast_exp(sacc[f][r] - lse) * (dpv - dsum) : 0.f;
-      }
-      store_acc_transposed<T>(dSs, PP, f * 32, ds, lane);
     }
-    wave_lds_sync();  // dS is wave-private
-    // dQ^T[c][q] += sum_key K[key][c] * dS^T[key][q]
 #pragma unroll
-    for (int kk = 0; kk < KB; kk += 16) {
-      Frag<T> bs = lds_frag(dSs, PP, 0, kk, lane);
+    for (int f = 0; f < KB / 32; ++f)
 #pragma unroll
-      for (int f = 0; f < NFC; ++f) {
-        Frag<T> ak = lds_frag_strided(Ks, PQ, kk, f * 32, lane);
-        mma32(dqacc[f], ak, bs);
+      for (int r = 0; r < 16; ++r) dpacc[f][r] = exp2_fast(sacc[f][r] - lse) * (dpacc[f][r] - dsum);  // dS^T
+    // dQ^T[c][q] += sum_key K[key][c] * dS^T[key][q]: dS^T from the accumulator registers, K read in the matching key order
+#pragma unroll
+    for (int f = 0; f < KB / 32; ++f)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const Frag<T> bs = frag_from_acc<T>(dpacc[f], t);
+#pragma unroll
+        for (int fc = 0; fc < NFC; ++fc) {
+          Frag<T> ak = lds_frag_strided_perm(Ks, PQ, f * 32 + 16 * t, fc * 32, lane);
+          mma32(dqacc[fc], ak, bs);
+        }
       }
-    }
   }
 
   if (q_ok) {
@@ -582,13 +627,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // =============================================================================================
-// backward dK, dV: wave = (sequence, head, 32-key block); the NW waves of a workgroup share the Q/dO tiles
+// backward dK, dV: wave = (sequence, head, 32-key block); the NW waves of a workgroup share the Q/dO tiles.
+// Here the scores are formed UNtransposed, S = Q K^T (queries along the accumulator rows, the wave's keys along lane&31), so that the
+// accumulator rows of P and dS are the contraction index of dV^T = dO^T P and dK^T = Q^T dS: both go from registers into the B operand
+// (see lds_frag_strided_perm) and the results come out as [channel rows][key lanes] — 4 consecutive channels of one key per register
+// group, stored with 8-byte writes.  The softmax statistics are per accumulator ROW here and are read from a small LDS table.
 // =============================================================================================
-template <typename T, int CP, int VEC, int NW>
+template <typename T, int CPK, int VEC, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int QB = 32;
   constexpr int PQ = lds_pitch<T>(CP);
-  constexpr int PT = lds_pitch<T>(QB);
   constexpr int NFC = CP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* sp = smem_raw;
@@ -596,16 +645,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   T* dOs = carve<T>(sp, QB * PQ);
   T* Ks_all = carve<T>(sp, NW * 32 * PQ);
   T* Vs_all = carve<T>(sp, NW * 32 * PQ);
-  T* PTs_all = carve<T>(sp, NW * 32 * PT);
-  T* dSTs_all = carve<T>(sp, NW * 32 * PT);
-  int* rq = carve<int>(sp, p.S);       // row index of every query of this sequence
+  float* stat = carve<float>(sp, 2 * QB);  // [lse * log2e | D] of the current query tile
+  int* rq = carve<int>(sp, p.S);           // row index of every query of this sequence
   int* rk_all = carve<int>(sp, NW * 32);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   T* Ks = Ks_all + wave * 32 * PQ;
   T* Vs = Vs_all + wave * 32 * PQ;
-  T* PTs = PTs_all + wave * 32 * PT;
-  T* dSTs = dSTs_all + wave * 32 * PT;
   int* rk = rk_all + wave * 32;
   const int nkb = (p.S + 31) / 32;
   const int nkg = (nkb + NW - 1) / NW;
@@ -623,15 +669,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   if (lane < 32) rk[lane] = (k0 + lane < p.S) ? seq_row(p.map, s, k0 + lane) : -1;
   __syncthreads();
   TileStager<T, CP, VEC, QB, 64 * NW> qst, dst;
-  float lse_n = 0.f, dsum_n = 0.f;  // softmax statistics of the prefetched query tile
+  float lse_n = 0.f, dsum_n = 0.f;  // softmax statistics of the prefetched query tile (threads 0..31)
   auto load_q = [&](int qb0) {
     const int nq = min(QB, p.S - qb0);
     qst.load(qkv, ld, head * p.c, rq + qb0, nq, p.c, tid);
     dst.load(dout, p.d, head * p.c, rq + qb0, nq, p.c, tid);
-    const int q = qb0 + (lane & 31);
-    const size_t si = ((size_t)s * p.h + head) * p.S + (q < p.S ? q : 0);
-    lse_n = p.lse[si];
-    dsum_n = p.dsum[si];
+    if (tid < QB) {
+      const int q = qb0 + tid;
+      const size_t si = ((size_t)s * p.h + head) * p.S + (q < p.S ? q : 0);
+      lse_n = p.lse[si];
+      dsum_n = p.dsum[si];
+    }
   };
   auto q_block_skipped = [&](int qb0) { return p.causal && qb0 + QB - 1 < k0_first; };  // all its queries precede every key of the workgroup
   int qb_next = 0;
@@ -651,76 +699,110 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   const bool drop = p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const int my_key = k0 + (lane & 31);
+  const bool key_dead = key_dead_flag(p, s, my_key) != 0;
 
   while (qb_next < p.S) {
     const int qb0 = qb_next;
     __syncthreads();
-    qst.store(Qs, PQ, p.scaling, tid);
+    qst.store(Qs, PQ, p.scaling * kLog2e, tid);  // scores in log2 units; dK is scaled back by ln 2 at the end
     dst.store(dOs, PQ, 1.0f, tid);
-    const float lse = lse_n, dsum = dsum_n;
+    if (tid < QB) {
+      stat[tid] = lse_n * kLog2e;
+      stat[QB + tid] = dsum_n;
+    }
     qb_next = qb0 + QB;
     if (qb_next < p.S) load_q(qb_next);  // next query tile (+ its statistics) in flight during this tile's math
     __syncthreads();
 
-    const int my_q = qb0 + (lane & 31);
-    const bool q_ok = my_q < p.S;
     const bool full_tile = !p.causal && p.kpm == nullptr && qb0 + QB <= p.S && k0 + 32 <= p.S;
 
     f32x16_t sacc = acc_zero(), dpacc = acc_zero();
 #pragma unroll
-    for (int kk = 0; kk < CP; kk += 16) {
-      Frag<T> bq = lds_frag(Qs, PQ, 0, kk, lane);
-      Frag<T> bd = lds_frag(dOs, PQ, 0, kk, lane);
-      Frag<T> ak = lds_frag(Ks, PQ, 0, kk, lane);
-      Frag<T> av = lds_frag(Vs, PQ, 0, kk, lane);
-      mma32(sacc, ak, bq);
-      mma32(dpacc, av, bd);
+    for (int kk = 0; kk < CPK; kk += 16) {
+      Frag<T> aq = lds_frag(Qs, PQ, 0, kk, lane);
+      Frag<T> ad = lds_frag(dOs, PQ, 0, kk, lane);
+      Frag<T> bk = lds_frag(Ks, PQ, 0, kk, lane);
+      Frag<T> bv = lds_frag(Vs, PQ, 0, kk, lane);
+      mma32(sacc, aq, bk);   // S  = Q K^T
+      mma32(dpacc, ad, bv);  // dP = dO V^T
     }
-    float pt[16], dsv[16];
+    if (!full_tile) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      bool vis = true;
-      if (!full_tile) {
-        const int key = k0 + acc_row(r, lane);
-        vis = q_ok && key_visible(p, s, key, my_q);
+      for (int r = 0; r < 16; ++r) {
+        const int q = qb0 + acc_row(r, lane);
+        const bool hide = key_dead || q >= p.S || (p.causal && my_key > q);
+        sacc[r] = hide ? -INFINITY : sacc[r];  // exp2 -> 0
       }
-      const float pv = vis ? fast_exp(sacc[r] - lse) : 0.f;
-      const float keep = drop ? attn_keep(p, seed, inv_keep, s, head, my_q, k0 + acc_row(r, lane)) : 1.0f;
-      pt[r] = pv * keep;                          // dV = (keep * P)^T dO
-      dsv[r] = pv * (dpacc[r] * keep - dsum);     // dS = P * (keep * dP - D)
     }
-    store_acc_natural<T>(PTs, PT, 0, 0, pt, lane);    // PTs[key][q]
-    store_acc_natural<T>(dSTs, PT, 0, 0, dsv, lane);  // dSTs[key][q]
-    wave_lds_sync();  // P^T and dS^T are wave-private
-    // dV[key][c] += sum_q P^T[key][q] dO[q][c] ;  dK[key][c] += sum_q dS^T[key][q] Qs[q][c]
+    if (drop) {
 #pragma unroll
-    for (int kk = 0; kk < QB; kk += 16) {
-      Frag<T> ap = lds_frag(PTs, PT, 0, kk, lane);
-      Frag<T> as = lds_frag(dSTs, PT, 0, kk, lane);
+      for (int r = 0; r < 16; ++r) {
+        const float keep = attn_keep(p, seed, inv_keep, s, head, qb0 + acc_row(r, lane), my_key);
+        const int i = r >> 2, e = r & 3;
+        const float pv = exp2_fast(sacc[r] - stat[8 * i + 4 * half + e]);
+        sacc[r] = pv * keep;                                                   // dV = (keep * P)^T dO
+        dpacc[r] = pv * (dpacc[r] * keep - stat[QB + 8 * i + 4 * half + e]);   // dS = P * (keep * dP - D)
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 l4 = *reinterpret_cast<const float4*>(stat + 8 * i + 4 * half);
+        const float4 d4 = *reinterpret_cast<const float4*>(stat + QB + 8 * i + 4 * half);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = exp2_fast(sacc[4 * i + e] - lv[e]);
+          sacc[4 * i + e] = pv;
+          dpacc[4 * i + e] = pv * (dpacc[4 * i + e] - dv[e]);
+        }
+      }
+    }
+    // dV^T[c][key] += sum_q dO[q][c] P[q][key] ;  dK^T[c][key] += sum_q Qs[q][c] dS[q][key]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const Frag<T> bp = frag_from_acc<T>(sacc, t);
+      const Frag<T> bs = frag_from_acc<T>(dpacc, t);
 #pragma unroll
       for (int f = 0; f < NFC; ++f) {
-        Frag<T> bdo = lds_frag_strided(dOs, PQ, kk, f * 32, lane);
-        Frag<T> bqq = lds_frag_strided(Qs, PQ, kk, f * 32, lane);
-        mma32(dvacc[f], ap, bdo);
-        mma32(dkacc[f], as, bqq);
+        Frag<T> ado = lds_frag_strided_perm(dOs, PQ, 16 * t, f * 32, lane);
+        Frag<T> aqq = lds_frag_strided_perm(Qs, PQ, 16 * t, f * 32, lane);
+        mma32(dvacc[f], ado, bp);
+        mma32(dkacc[f], aqq, bs);
       }
     }
   }
 
-  T* dqkv = reinterpret_cast<T*>(p.dqkv);
+  if (my_key < p.S) {
+    T* dqkv = reinterpret_cast<T*>(p.dqkv);
+    const size_t row = (size_t)rk[lane & 31];
 #pragma unroll
-  for (int f = 0; f < NFC; ++f) {
-    const int col = f * 32 + (lane & 31);
-    if (col >= p.c) continue;
+    for (int f = 0; f < NFC; ++f)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kr = acc_row(r, lane);
-      if (k0 + kr < p.S) {
-        const size_t row = (size_t)rk[kr];
-        dqkv[row * ld + p.d + head * p.c + col] = from_f<T>(dkacc[f][r]);
-        dqkv[row * ld + 2 * p.d + head * p.c + col] = from_f<T>(dvacc[f][r]);
+      for (int i = 0; i < 4; ++i) {
+        const int cb = f * 32 + 8 * i + 4 * half;
+        float dk[4], dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dk[e] = dkacc[f][4 * i + e] * kLn2;
+          dv[e] = dvacc[f][4 * i + e];
+        }
+        T* pk = dqkv + row * ld + p.d + head * p.c + cb;
+        T* pv = dqkv + row * ld + 2 * p.d + head * p.c + cb;
+        if (VEC == 4) {
+          if (cb < p.c) {
+            st_vec<T, 4>(pk, dk);
+            st_vec<T, 4>(pv, dv);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (cb + e < p.c) {
+              pk[e] = from_f<T>(dk[e]);
+              pv[e] = from_f<T>(dv[e]);
+            }
+        }
       }
-    }
   }
 }
 
@@ -740,52 +822,59 @@ static AttnParams make_params(const void* qkv, void* out, const void* dout, void
 
 enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
 
-template <typename T, int CP, int NW> static size_t attn_smem(int which, int S) {
-  const size_t PQ = lds_pitch<T>(CP), PP = lds_pitch<T>(64), PT = lds_pitch<T>(32), e = sizeof(T);
+template <typename T, int CPK, int NW> static size_t attn_smem(int which, int S) {
+  constexpr int CP = (CPK + 31) / 32 * 32;
+  const size_t PQ = lds_pitch<T>(CP), e = sizeof(T);
+  const size_t KB = NW == 1 ? 32 : 64;
   size_t b = carve_bytes(S, 4) + carve_bytes(NW * 32, 4);
-  if (which == K_FWD) b += 2 * carve_bytes(64 * PQ, e) + carve_bytes(NW * 32 * PQ, e) + carve_bytes(NW * 32 * PP, e);
-  else if (which == K_DQ) b += 2 * carve_bytes(64 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + carve_bytes(NW * 32 * PP, e);
-  else b += 2 * carve_bytes(32 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + 2 * carve_bytes(NW * 32 * PT, e);
+  if (which != K_DKV) b += carve_bytes((S + 63) & ~63, 4);
+  if (which == K_FWD) b += 2 * carve_bytes(KB * PQ, e) + carve_bytes(NW * 32 * PQ, e);
+  else if (which == K_DQ) b += 2 * carve_bytes(KB * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e);
+  else b += 2 * carve_bytes(32 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + carve_bytes(64, 4);
   return b;
 }
 
-template <typename T, int CP, int VEC, int NW>
+template <typename T, int CPK, int VEC, int NW>
 static int launch_attn(int which, const AttnParams& p, hipStream_t st) {
-  const size_t smem = attn_smem<T, CP, NW>(which, p.S);
+  const size_t smem = attn_smem<T, CPK, NW>(which, p.S);
   if (smem > 160 * 1024) return -2;
   const int nb = (p.S + 31) / 32;
   const int grid = p.nseq * p.h * ((nb + NW - 1) / NW);
-  const void* fn = which == K_FWD ? reinterpret_cast<const void*>(attn_fwd_kernel<T, CP, VEC, NW>)
-                   : which == K_DQ ? reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, CP, VEC, NW>)
-                                   : reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, CP, VEC, NW>);
+  const void* fn = which == K_FWD ? reinterpret_cast<const void*>(attn_fwd_kernel<T, CPK, VEC, NW>)
+                   : which == K_DQ ? reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, CPK, VEC, NW>)
+                                   : reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, CPK, VEC, NW>);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  if (which == K_FWD) hipLaunchKernelGGL((attn_fwd_kernel<T, CP, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
-  else if (which == K_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, CP, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
-  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, CP, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  if (which == K_FWD) hipLaunchKernelGGL((attn_fwd_kernel<T, CPK, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  else if (which == K_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, CPK, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, CPK, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
   CVH_CHECK_LAUNCH();
   return 0;
 }
 
-template <typename T, int CP, int VEC>
+template <typename T, int CPK, int VEC>
 static int dispatch_nw(int which, const AttnParams& p, hipStream_t st) {
   const int nb = (p.S + 31) / 32;
-  if (nb >= 4) return launch_attn<T, CP, VEC, 4>(which, p, st);
-  if (nb >= 2) return launch_attn<T, CP, VEC, 2>(which, p, st);
-  return launch_attn<T, CP, VEC, 1>(which, p, st);
+  if (nb >= 4) return launch_attn<T, CPK, VEC, 4>(which, p, st);
+  if (nb >= 2) return launch_attn<T, CPK, VEC, 2>(which, p, st);
+  return launch_attn<T, CPK, VEC, 1>(which, p, st);
 }
-template <typename T, int CP>
+template <typename T, int CPK>
 static int dispatch_vec(int which, const AttnParams& p, hipStream_t st) {
-  if (p.c % 4 == 0) return dispatch_nw<T, CP, 4>(which, p, st);
-  if (p.c % 2 == 0) return dispatch_nw<T, CP, 2>(which, p, st);
-  return dispatch_nw<T, CP, 1>(which, p, st);
+  if (p.c % 4 == 0) return dispatch_nw<T, CPK, 4>(which, p, st);
+  return dispatch_nw<T, CPK, 1>(which, p, st);
+}
+template <typename T>
+static int dispatch_cpk(int which, const AttnParams& p, hipStream_t st) {
+  if (p.c <= 32) return dispatch_vec<T, 32>(which, p, st);
+  if (p.c <= 48) return dispatch_vec<T, 48>(which, p, st);
+  return dispatch_vec<T, 64>(which, p, st);
 }
 static int dispatch_attn(int dtype, int which, const AttnParams& p, hipStream_t st) {
-  const bool cp32 = p.c <= 32;
-  if (dtype == CVH_DT_BF16) return cp32 ? dispatch_vec<bf16_t, 32>(which, p, st) : dispatch_vec<bf16_t, 64>(which, p, st);
-  if (dtype == CVH_DT_F32) return cp32 ? dispatch_vec<float, 32>(which, p, st) : dispatch_vec<float, 64>(which, p, st);
+  if (dtype == CVH_DT_BF16) return dispatch_cpk<bf16_t>(which, p, st);
+  if (dtype == CVH_DT_F32) return dispatch_cpk<float>(which, p, st);
   return -1;
 }
 

@@ -16,6 +16,9 @@
 #include "common.hpp"
 #include "cvnets_hip.h"
 
+#ifndef ATTN_WPE
+#define ATTN_WPE 2
+#endif
 struct AttnParams {
   const void* qkv;   // T [rows][3d]
   void* out;         // fwd: T [rows][d]
@@ -164,6 +167,74 @@ struct TileStager {
   }
 };
 
+// Two [NROWS x CP] tiles that share their row list (K and V of one key tile; Q and dO of one query tile), prefetched into registers by
+// NT threads a whole tile ahead of their use.  The row list is PADDED to a multiple of the tile height with -1 (absent row), so the hot
+// loop has no bounds tests and no branches: all row indices are read from LDS first, then all global loads are issued from clamped
+// addresses; validity is applied when the registers are written to LDS.  One row index read and (for equal leading dimensions) one
+// 64-bit address product serve both tiles.  (The per-tile TileStager pair above cost as many instructions per tile as the softmax.)
+template <typename T, int CP, int VEC, int NROWS, int NT>
+struct PairStager {
+  static constexpr int CH = CP / VEC;
+  static constexpr int IT = (NROWS * CH + NT - 1) / NT;
+  static constexpr bool EXACT = (NROWS * CH) % NT == 0;
+  V4<T> qa[VEC == 4 ? IT : 1], qb[VEC == 4 ? IT : 1];
+  T ea[VEC == 4 ? 1 : IT], eb[VEC == 4 ? 1 : IT];
+  unsigned okm;
+
+  // ga / gb already point at column 0 of the wanted column block; rows = padded row list of this tile
+  __device__ __forceinline__ void load(const T* __restrict__ ga, int lda, const T* __restrict__ gb, int ldb, const int* rows, int c, int tid) {
+    int ri[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      ri[it] = rows[(EXACT || idx < NROWS * CH) ? idx / CH : 0];
+    }
+    okm = 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      const int cc = (idx % CH) * VEC;
+      const bool ok = (EXACT || idx < NROWS * CH) && cc < c && ri[it] >= 0;
+      okm |= (ok ? 1u : 0u) << it;
+      const size_t oa = ok ? (size_t)ri[it] * lda + cc : (size_t)0;
+      const size_t ob = ok ? (size_t)ri[it] * ldb + cc : (size_t)0;
+      if constexpr (VEC == 4) {
+        qa[it] = v4_load<T>(ga + oa);
+        qb[it] = v4_load<T>(gb + ob);
+      } else {
+        ea[it] = ga[oa];
+        eb[it] = gb[ob];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(T* la, float scale_a, T* lb, int pitch, int tid) const {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + it * NT;
+      if (!EXACT && idx >= NROWS * CH) continue;
+      const int r = idx / CH, cc = (idx % CH) * VEC;
+      const bool ok = (okm >> it) & 1u;
+      if constexpr (VEC == 4) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        V4<T> zero, va = qa[it], vb = qb[it];
+        v4_pack(z, zero);
+        if (scale_a != 1.0f) {
+          float f[4];
+          v4_unpack(va, f);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[k] *= scale_a;
+          v4_pack(f, va);
+        }
+        v4_store<T>(la + r * pitch + cc, ok ? va : zero);
+        v4_store<T>(lb + r * pitch + cc, ok ? vb : zero);
+      } else {
+        la[r * pitch + cc] = ok ? from_f<T>(to_f<T>(ea[it]) * scale_a) : from_f<T>(0.f);
+        lb[r * pitch + cc] = ok ? eb[it] : from_f<T>(0.f);
+      }
+    }
+  }
+};
+
 // operand fragment read "down the rows" of a row-major [k][n] LDS tile (the transposed operand):
 // element j = tile[k0 + 8*(lane>>5) + j][col0 + (lane&31)]
 // bf16: two gfx950 LDS transpose reads (ds_read_b64_tr_b16).  Inside a 16-lane group lane i = 4r + q supplies the address of 4
@@ -232,8 +303,9 @@ constexpr float kLn2 = 0.6931471805599453f;
 
 // Key visibility without per-score branches: every kernel builds, once, a table (LDS) or a per-lane flag of the keys that no query may
 // see (beyond the sequence end, or set in the key padding mask); the causal rule is a compare.  Masked scores become -inf, so exp2 -> 0.
-__device__ __forceinline__ int key_dead_flag(const AttnParams& p, int s, int key) {
+template <int FEAT> __device__ __forceinline__ int key_dead_flag(const AttnParams& p, int s, int key) {
   if (key >= p.S) return 1;
+  if (!FEAT) return 0;
   return (p.kpm && p.kpm[(size_t)s * p.S + key]) ? 1 : 0;
 }
 
@@ -252,18 +324,19 @@ static size_t carve_bytes(size_t elems, size_t esz) { return (elems * esz + 15) 
 // =============================================================================================
 // CPK = head width rounded up to the 16-wide MFMA k-step (the contraction length of Q K^T); the LDS tiles and the output fragments are
 // CP = CPK rounded up to 32 columns wide (columns >= c are zero).
-template <typename T, int CPK, int VEC, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
+template <typename T, int CPK, int VEC, int NW, int FEAT>
+__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_fwd_kernel(AttnParams p) {
   constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int NFC = CP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const bool causal = FEAT && p.causal;  // FEAT == 0: no causal rule, no key padding mask, no dropout (compiled out)
   char* sp = smem_raw;
   T* Ks = carve<T>(sp, KB * PQ);
   T* Vs = carve<T>(sp, KB * PQ);
   T* Qs_all = carve<T>(sp, NW * 32 * PQ);
-  int* rk = carve<int>(sp, p.S);       // row index of every key of this sequence
+  int* rk = carve<int>(sp, (p.S + 63) & ~63);  // row index of every key of this sequence, -1 padded to the tile height
   int* rq_all = carve<int>(sp, NW * 32);
   int* kd = carve<int>(sp, (p.S + 63) & ~63);  // 1 = key can never be seen
 
@@ -283,16 +356,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   const T* qkv = reinterpret_cast<const T*>(p.qkv);
   const int ld = 3 * p.d;
 
-  for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
-  for (int i = tid; i < ((p.S + 63) & ~63); i += 64 * NW) kd[i] = key_dead_flag(p, s, i);
+  for (int i = tid; i < ((p.S + 63) & ~63); i += 64 * NW) {
+    rk[i] = i < p.S ? seq_row(p.map, s, i) : -1;
+    kd[i] = key_dead_flag<FEAT>(p, s, i);
+  }
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
-  TileStager<T, CP, VEC, KB, 64 * NW> kst, vst;
-  auto load_kv = [&](int kv0) {
-    const int nk = min(KB, p.S - kv0);
-    kst.load(qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, tid);
-    vst.load(qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, tid);
-  };
+  PairStager<T, CP, VEC, KB, 64 * NW> kvst;
+  const T* kcol = qkv + p.d + head * p.c;
+  auto load_kv = [&](int kv0) { kvst.load(kcol, ld, kcol + p.d, ld, rk + kv0, p.c, tid); };
   {
     TileStager<T, CP, VEC, 32, 64> qst;
     qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
@@ -301,7 +373,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   }
 
   const int my_q = q0 + (lane & 31);
-  const bool drop = p.drop_p > 0.f;
+  const bool drop = FEAT && p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   float m_run = -1e30f, l_run = 0.f;  // running max (log2 units) and normaliser
@@ -310,13 +382,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
   for (int f = 0; f < NFC; ++f) oacc[f] = acc_zero();
 
   for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
-    if (p.causal && kv0 > q0_last + 31) break;  // tile entirely in the future of every query of the workgroup
+    if (causal && kv0 > q0_last + 31) break;  // tile entirely in the future of every query of the workgroup
     __syncthreads();                             // previous tile's K/V (and this wave's P) fully consumed
-    kst.store(Ks, PQ, 1.0f, tid);                // rows past the sequence end arrive as zeros (V rows feed the MFMA k-dimension)
-    vst.store(Vs, PQ, 1.0f, tid);
+    kvst.store(Ks, 1.0f, Vs, PQ, tid);           // rows past the sequence end arrive as zeros (V rows feed the MFMA k-dimension)
     if (kv0 + KB < p.S) load_kv(kv0 + KB);       // next tile's HBM reads fly under this tile's MFMA + softmax
     __syncthreads();
-    const bool full_tile = !p.causal && p.kpm == nullptr && kv0 + KB <= p.S;  // workgroup-uniform: no per-element visibility tests
+    const bool full_tile = !causal && (!FEAT || p.kpm == nullptr) && kv0 + KB <= p.S;  // workgroup-uniform: no per-element visibility tests
 
     // S^T[key][q] = sum_c K[key][c] * Qs[q][c]
     f32x16_t sacc[KB / 32];
@@ -341,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnParams p) {
           const int dead[4] = {dd.x, dd.y, dd.z, dd.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool hide = dead[e] != 0 || (p.causal && key0 + e > my_q);
+            const bool hide = dead[e] != 0 || (causal && key0 + e > my_q);
             sacc[f][4 * i + e] = hide ? -INFINITY : sacc[f][4 * i + e];
           }
         }
@@ -476,19 +547,20 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_rows_kernel(const T* __rest
 // =============================================================================================
 // backward dQ: wave = (sequence, head, 32-query block); the NW waves of a workgroup share the K/V tiles
 // =============================================================================================
-template <typename T, int CPK, int VEC, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
+template <typename T, int CPK, int VEC, int NW, int FEAT>
+__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int NFC = CP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const bool causal = FEAT && p.causal;  // FEAT == 0: no causal rule, no key padding mask, no dropout (compiled out)
   char* sp = smem_raw;
   T* Ks = carve<T>(sp, KB * PQ);
   T* Vs = carve<T>(sp, KB * PQ);
   T* Qs_all = carve<T>(sp, NW * 32 * PQ);
   T* dOs_all = carve<T>(sp, NW * 32 * PQ);
-  int* rk = carve<int>(sp, p.S);
+  int* rk = carve<int>(sp, (p.S + 63) & ~63);
   int* rq_all = carve<int>(sp, NW * 32);
   int* kd = carve<int>(sp, (p.S + 63) & ~63);  // 1 = key can never be seen
 
@@ -510,16 +582,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   const T* dout = reinterpret_cast<const T*>(p.dout);
   const int ld = 3 * p.d;
 
-  for (int i = tid; i < p.S; i += 64 * NW) rk[i] = seq_row(p.map, s, i);
-  for (int i = tid; i < ((p.S + 63) & ~63); i += 64 * NW) kd[i] = key_dead_flag(p, s, i);
+  for (int i = tid; i < ((p.S + 63) & ~63); i += 64 * NW) {
+    rk[i] = i < p.S ? seq_row(p.map, s, i) : -1;
+    kd[i] = key_dead_flag<FEAT>(p, s, i);
+  }
   if (lane < 32) rq[lane] = (q0 + lane < p.S) ? seq_row(p.map, s, q0 + lane) : -1;
   __syncthreads();
-  TileStager<T, CP, VEC, KB, 64 * NW> kst, vst;
-  auto load_kv = [&](int kv0) {
-    const int nk = min(KB, p.S - kv0);
-    kst.load(qkv, ld, p.d + head * p.c, rk + kv0, nk, p.c, tid);
-    vst.load(qkv, ld, 2 * p.d + head * p.c, rk + kv0, nk, p.c, tid);
-  };
+  PairStager<T, CP, VEC, KB, 64 * NW> kvst;
+  const T* kcol = qkv + p.d + head * p.c;
+  auto load_kv = [&](int kv0) { kvst.load(kcol, ld, kcol + p.d, ld, rk + kv0, p.c, tid); };
   {
     TileStager<T, CP, VEC, 32, 64> qst, dst;
     qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
@@ -533,7 +604,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   const bool q_ok = my_q < p.S;
   const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
   const float lse = p.lse[sidx] * kLog2e, dsum = p.dsum[sidx];
-  const bool drop = p.drop_p > 0.f;
+  const bool drop = FEAT && p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
@@ -542,13 +613,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
   for (int f = 0; f < NFC; ++f) dqacc[f] = acc_zero();
 
   for (int kv0 = 0; kv0 < p.S; kv0 += KB) {
-    if (p.causal && kv0 > q0_last + 31) break;
+    if (causal && kv0 > q0_last + 31) break;
     __syncthreads();
-    kst.store(Ks, PQ, 1.0f, tid);
-    vst.store(Vs, PQ, 1.0f, tid);
+    kvst.store(Ks, 1.0f, Vs, PQ, tid);
     if (kv0 + KB < p.S) load_kv(kv0 + KB);
     __syncthreads();
-    const bool full_tile = !p.causal && p.kpm == nullptr && kv0 + KB <= p.S;
+    const bool full_tile = !causal && (!FEAT || p.kpm == nullptr) && kv0 + KB <= p.S;
 
     f32x16_t sacc[KB / 32], dpacc[KB / 32];
 #pragma unroll
@@ -581,7 +651,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
           const int dead[4] = {dd.x, dd.y, dd.z, dd.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool hide = !q_ok || dead[e] != 0 || (p.causal && key0 + e > my_q);
+            const bool hide = !q_ok || dead[e] != 0 || (causal && key0 + e > my_q);
             sacc[f][4 * i + e] = hide ? -INFINITY : sacc[f][4 * i + e];  // exp2 -> 0
           }
         }
@@ -633,20 +703,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnParams p) {
 // (see lds_frag_strided_perm) and the results come out as [channel rows][key lanes] — 4 consecutive channels of one key per register
 // group, stored with 8-byte writes.  The softmax statistics are per accumulator ROW here and are read from a small LDS table.
 // =============================================================================================
-template <typename T, int CPK, int VEC, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
+template <typename T, int CPK, int VEC, int NW, int FEAT>
+__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int QB = 32;
   constexpr int PQ = lds_pitch<T>(CP);
   constexpr int NFC = CP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const bool causal = FEAT && p.causal;  // FEAT == 0: no causal rule, no key padding mask, no dropout (compiled out)
   char* sp = smem_raw;
   T* Qs = carve<T>(sp, QB * PQ);
   T* dOs = carve<T>(sp, QB * PQ);
   T* Ks_all = carve<T>(sp, NW * 32 * PQ);
   T* Vs_all = carve<T>(sp, NW * 32 * PQ);
   float* stat = carve<float>(sp, 2 * QB);  // [lse * log2e | D] of the current query tile
-  int* rq = carve<int>(sp, p.S);           // row index of every query of this sequence
+  int* rq = carve<int>(sp, (p.S + 31) & ~31);  // row index of every query of this sequence, -1 padded to the tile height
   int* rk_all = carve<int>(sp, NW * 32);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -665,15 +736,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   const T* dout = reinterpret_cast<const T*>(p.dout);
   const int ld = 3 * p.d;
 
-  for (int i = tid; i < p.S; i += 64 * NW) rq[i] = seq_row(p.map, s, i);
+  for (int i = tid; i < ((p.S + 31) & ~31); i += 64 * NW) rq[i] = i < p.S ? seq_row(p.map, s, i) : -1;
   if (lane < 32) rk[lane] = (k0 + lane < p.S) ? seq_row(p.map, s, k0 + lane) : -1;
   __syncthreads();
-  TileStager<T, CP, VEC, QB, 64 * NW> qst, dst;
+  PairStager<T, CP, VEC, QB, 64 * NW> qdst;
   float lse_n = 0.f, dsum_n = 0.f;  // softmax statistics of the prefetched query tile (threads 0..31)
   auto load_q = [&](int qb0) {
-    const int nq = min(QB, p.S - qb0);
-    qst.load(qkv, ld, head * p.c, rq + qb0, nq, p.c, tid);
-    dst.load(dout, p.d, head * p.c, rq + qb0, nq, p.c, tid);
+    qdst.load(qkv + head * p.c, ld, dout + head * p.c, p.d, rq + qb0, p.c, tid);
     if (tid < QB) {
       const int q = qb0 + tid;
       const size_t si = ((size_t)s * p.h + head) * p.S + (q < p.S ? q : 0);
@@ -681,7 +750,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
       dsum_n = p.dsum[si];
     }
   };
-  auto q_block_skipped = [&](int qb0) { return p.causal && qb0 + QB - 1 < k0_first; };  // all its queries precede every key of the workgroup
+  auto q_block_skipped = [&](int qb0) { return causal && qb0 + QB - 1 < k0_first; };  // all its queries precede every key of the workgroup
   int qb_next = 0;
   while (qb_next < p.S && q_block_skipped(qb_next)) qb_next += QB;
   {
@@ -696,17 +765,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
   f32x16_t dkacc[NFC], dvacc[NFC];
 #pragma unroll
   for (int f = 0; f < NFC; ++f) { dkacc[f] = acc_zero(); dvacc[f] = acc_zero(); }
-  const bool drop = p.drop_p > 0.f;
+  const bool drop = FEAT && p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const int my_key = k0 + (lane & 31);
-  const bool key_dead = key_dead_flag(p, s, my_key) != 0;
+  const bool key_dead = key_dead_flag<FEAT>(p, s, my_key) != 0;
 
   while (qb_next < p.S) {
     const int qb0 = qb_next;
     __syncthreads();
-    qst.store(Qs, PQ, p.scaling * kLog2e, tid);  // scores in log2 units; dK is scaled back by ln 2 at the end
-    dst.store(dOs, PQ, 1.0f, tid);
+    qdst.store(Qs, p.scaling * kLog2e, dOs, PQ, tid);  // scores in log2 units; dK is scaled back by ln 2 at the end
     if (tid < QB) {
       stat[tid] = lse_n * kLog2e;
       stat[QB + tid] = dsum_n;
@@ -715,7 +783,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
     if (qb_next < p.S) load_q(qb_next);  // next query tile (+ its statistics) in flight during this tile's math
     __syncthreads();
 
-    const bool full_tile = !p.causal && p.kpm == nullptr && qb0 + QB <= p.S && k0 + 32 <= p.S;
+    const bool full_tile = !causal && (!FEAT || p.kpm == nullptr) && qb0 + QB <= p.S && k0 + 32 <= p.S;
 
     f32x16_t sacc = acc_zero(), dpacc = acc_zero();
 #pragma unroll
@@ -731,7 +799,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = qb0 + acc_row(r, lane);
-        const bool hide = key_dead || q >= p.S || (p.causal && my_key > q);
+        const bool hide = key_dead || q >= p.S || (causal && my_key > q);
         sacc[r] = hide ? -INFINITY : sacc[r];  // exp2 -> 0
       }
     }
@@ -826,34 +894,39 @@ template <typename T, int CPK, int NW> static size_t attn_smem(int which, int S)
   constexpr int CP = (CPK + 31) / 32 * 32;
   const size_t PQ = lds_pitch<T>(CP), e = sizeof(T);
   const size_t KB = NW == 1 ? 32 : 64;
-  size_t b = carve_bytes(S, 4) + carve_bytes(NW * 32, 4);
-  if (which != K_DKV) b += carve_bytes((S + 63) & ~63, 4);
+  size_t b = carve_bytes(NW * 32, 4);
+  b += which != K_DKV ? 2 * carve_bytes((S + 63) & ~63, 4) : carve_bytes((S + 31) & ~31, 4);
   if (which == K_FWD) b += 2 * carve_bytes(KB * PQ, e) + carve_bytes(NW * 32 * PQ, e);
   else if (which == K_DQ) b += 2 * carve_bytes(KB * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e);
   else b += 2 * carve_bytes(32 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + carve_bytes(64, 4);
   return b;
 }
 
-template <typename T, int CPK, int VEC, int NW>
-static int launch_attn(int which, const AttnParams& p, hipStream_t st) {
+template <typename T, int CPK, int VEC, int NW, int FEAT>
+static int launch_attn_feat(int which, const AttnParams& p, hipStream_t st) {
   const size_t smem = attn_smem<T, CPK, NW>(which, p.S);
   if (smem > 160 * 1024) return -2;
   const int nb = (p.S + 31) / 32;
   const int grid = p.nseq * p.h * ((nb + NW - 1) / NW);
-  const void* fn = which == K_FWD ? reinterpret_cast<const void*>(attn_fwd_kernel<T, CPK, VEC, NW>)
-                   : which == K_DQ ? reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, CPK, VEC, NW>)
-                                   : reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, CPK, VEC, NW>);
+  const void* fn = which == K_FWD ? reinterpret_cast<const void*>(attn_fwd_kernel<T, CPK, VEC, NW, FEAT>)
+                   : which == K_DQ ? reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, CPK, VEC, NW, FEAT>)
+                                   : reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, CPK, VEC, NW, FEAT>);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  if (which == K_FWD) hipLaunchKernelGGL((attn_fwd_kernel<T, CPK, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
-  else if (which == K_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, CPK, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
-  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, CPK, VEC, NW>), dim3(grid), dim3(64 * NW), smem, st, p);
+  if (which == K_FWD) hipLaunchKernelGGL((attn_fwd_kernel<T, CPK, VEC, NW, FEAT>), dim3(grid), dim3(64 * NW), smem, st, p);
+  else if (which == K_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, CPK, VEC, NW, FEAT>), dim3(grid), dim3(64 * NW), smem, st, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, CPK, VEC, NW, FEAT>), dim3(grid), dim3(64 * NW), smem, st, p);
   CVH_CHECK_LAUNCH();
   return 0;
 }
 
+template <typename T, int CPK, int VEC, int NW>
+static int launch_attn(int which, const AttnParams& p, hipStream_t st) {
+  const bool feat = p.causal || p.kpm != nullptr || p.drop_p > 0.f;
+  return feat ? launch_attn_feat<T, CPK, VEC, NW, 1>(which, p, st) : launch_attn_feat<T, CPK, VEC, NW, 0>(which, p, st);
+}
 template <typename T, int CPK, int VEC>
 static int dispatch_nw(int which, const AttnParams& p, hipStream_t st) {
   const int nb = (p.S + 31) / 32;

@@ -16,8 +16,14 @@
 #include "common.hpp"
 #include "cvnets_hip.h"
 
-#ifndef ATTN_WPE
-#define ATTN_WPE 2
+#ifndef ATTN_WPE_F
+#define ATTN_WPE_F 2
+#endif
+#ifndef ATTN_WPE_Q
+#define ATTN_WPE_Q 2
+#endif
+#ifndef ATTN_WPE_K
+#define ATTN_WPE_K 2
 #endif
 struct AttnParams {
   const void* qkv;   // T [rows][3d]
@@ -137,6 +143,22 @@ struct TileStager {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) e[it][k] = (ri >= 0) ? g[(size_t)ri * ld + col0 + cc + k] : from_f<T>(0.f);
       }
+    }
+  }
+  // sum over this thread's VEC elements of iteration `it` of the product with another stager loaded over the same rows / columns
+  __device__ __forceinline__ float dot(const TileStager& o, int it) const {
+    float s = 0.f;
+    if constexpr (VEC == 4) {
+      float a[4], b[4];
+      v4_unpack(q[it], a);
+      v4_unpack(o.q[it], b);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += a[k] * b[k];
+      return ((okm >> it) & 1u) ? s : 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) s += to_f<T>(e[it][k]) * to_f<T>(o.e[it][k]);
+      return s;
     }
   }
   __device__ __forceinline__ void store(T* lds, int pitch, float scale, int tid) const {
@@ -325,7 +347,7 @@ static size_t carve_bytes(size_t elems, size_t esz) { return (elems * esz + 15) 
 // CPK = head width rounded up to the 16-wide MFMA k-step (the contraction length of Q K^T); the LDS tiles and the output fragments are
 // CP = CPK rounded up to 32 columns wide (columns >= c are zero).
 template <typename T, int CPK, int VEC, int NW, int FEAT>
-__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_F) void attn_fwd_kernel(AttnParams p) {
   constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
@@ -487,68 +509,10 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_fwd_kernel(
 }
 
 // =============================================================================================
-// backward prep: D[s,h,n] = sum_c dO * O
-// =============================================================================================
-template <typename T, int VEC>
-__global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, AttnParams p) {
-  const size_t total = (size_t)p.nseq * p.h * p.S;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int head = (int)(idx % p.h);           // heads fastest: neighbouring lanes read neighbouring columns of one row
-    const int n = (int)((idx / p.h) % p.S);
-    const int s = (int)(idx / ((size_t)p.S * p.h));
-    const size_t row = (size_t)seq_row(p.map, s, n);
-    float acc = 0.f;
-    for (int cc = 0; cc < p.c; cc += VEC) {
-      float a[VEC], b[VEC];
-      ld_vec<T, VEC>(o + row * p.d + head * p.c + cc, a);
-      ld_vec<T, VEC>(dout + row * p.d + head * p.c + cc, b);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) acc += a[e] * b[e];
-    }
-    p.dsum[((size_t)s * p.h + head) * p.S + n] = acc;
-  }
-}
-
-// c % 4 == 0: lanes run ALONG the row (8-byte chunks of 4 channels, so a wave reads 512 contiguous bytes instead of 64 separate
-// cache lines) and the per-head sums are formed with LDS float atomics.  Block = 8 tokens x all d/4 chunks.
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_prep_rows_kernel(const T* __restrict__ o, const T* __restrict__ dout, AttnParams p) {
-  constexpr int TB = 8;
-  __shared__ float acc[TB * 64];  // [token][head], h <= 64
-  __shared__ int rows[TB];
-  const int cpr = p.d / 4;  // chunks per row
-  const size_t ntok = (size_t)p.nseq * p.S;
-  for (size_t t0 = (size_t)blockIdx.x * TB; t0 < ntok; t0 += (size_t)gridDim.x * TB) {
-    for (int i = threadIdx.x; i < TB * p.h; i += 256) acc[i] = 0.f;
-    if (threadIdx.x < TB) {
-      const size_t t = t0 + threadIdx.x;
-      rows[threadIdx.x] = t < ntok ? seq_row(p.map, (int)(t / p.S), (int)(t % p.S)) : -1;
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < TB * cpr; idx += 256) {
-      const int tl = idx / cpr, ch = idx - tl * cpr;
-      const int row = rows[tl];
-      if (row < 0) continue;
-      float a[4], b[4];
-      v4_unpack(v4_load<T>(o + (size_t)row * p.d + ch * 4), a);
-      v4_unpack(v4_load<T>(dout + (size_t)row * p.d + ch * 4), b);
-      atomicAdd(&acc[tl * p.h + (ch * 4) / p.c], (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]));
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < TB * p.h; i += 256) {
-      const int tl = i / p.h, head = i - tl * p.h;
-      const size_t t = t0 + tl;
-      if (t < ntok) p.dsum[((size_t)(t / p.S) * p.h + head) * p.S + (t % p.S)] = acc[i];
-    }
-    __syncthreads();
-  }
-}
-
-// =============================================================================================
 // backward dQ: wave = (sequence, head, 32-query block); the NW waves of a workgroup share the K/V tiles
 // =============================================================================================
 template <typename T, int CPK, int VEC, int NW, int FEAT>
-__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_Q) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int KB = (NW == 1) ? 32 : 64;  // NW == 1 <=> S <= 32: one 32-key tile covers the sequence
   constexpr int PQ = lds_pitch<T>(CP);
@@ -562,6 +526,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dq_kern
   T* dOs_all = carve<T>(sp, NW * 32 * PQ);
   int* rk = carve<int>(sp, (p.S + 63) & ~63);
   int* rq_all = carve<int>(sp, NW * 32);
+  float* dw_all = carve<float>(sp, NW * 32);
   int* kd = carve<int>(sp, (p.S + 63) & ~63);  // 1 = key can never be seen
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -591,19 +556,36 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dq_kern
   PairStager<T, CP, VEC, KB, 64 * NW> kvst;
   const T* kcol = qkv + p.d + head * p.c;
   auto load_kv = [&](int kv0) { kvst.load(kcol, ld, kcol + p.d, ld, rk + kv0, p.c, tid); };
-  {
-    TileStager<T, CP, VEC, 32, 64> qst, dst;
-    qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
-    dst.load(dout, p.d, head * p.c, rq, 32, p.c, lane);
-    load_kv(0);
-    qst.store(Qs, PQ, p.scaling * kLog2e, lane);  // scores in log2 units
-    dst.store(dOs, PQ, 1.0f, lane);
-  }
-
   const int my_q = q0 + (lane & 31);
   const bool q_ok = my_q < p.S;
   const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
-  const float lse = p.lse[sidx] * kLog2e, dsum = p.dsum[sidx];
+  float dsum;
+  {
+    // D[q] = sum_c dO[q][c] * O[q][c] of this wave's 32 queries, formed here from the dO tile on its way into LDS and the matching O
+    // rows (no separate pass over dO and O), and published for the dK/dV kernel that runs next
+    typedef TileStager<T, CP, VEC, 32, 64> QS;
+    QS qst, dst, ost;
+    qst.load(qkv, ld, head * p.c, rq, 32, p.c, lane);
+    dst.load(dout, p.d, head * p.c, rq, 32, p.c, lane);
+    ost.load(reinterpret_cast<const T*>(p.out), p.d, head * p.c, rq, 32, p.c, lane);
+    load_kv(0);
+    qst.store(Qs, PQ, p.scaling * kLog2e, lane);  // scores in log2 units
+    dst.store(dOs, PQ, 1.0f, lane);
+    float* dw = dw_all + wave * 32;
+    constexpr int CH = QS::CH, RPI = 64 / CH;  // a row's chunks sit in CH consecutive lanes
+    static_assert(64 % CH == 0 && QS::IT * RPI == 32, "stager layout");
+#pragma unroll
+    for (int it = 0; it < QS::IT; ++it) {
+      float v = dst.dot(ost, it);
+#pragma unroll
+      for (int m = CH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (lane % CH == 0) dw[it * RPI + lane / CH] = v;
+    }
+    wave_lds_sync();
+    dsum = dw[lane & 31];
+    if (lane < 32 && q_ok) p.dsum[sidx] = dsum;
+  }
+  const float lse = p.lse[sidx] * kLog2e;
   const bool drop = FEAT && p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -704,7 +686,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dq_kern
 // group, stored with 8-byte writes.  The softmax statistics are per accumulator ROW here and are read from a small LDS table.
 // =============================================================================================
 template <typename T, int CPK, int VEC, int NW, int FEAT>
-__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_K) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int CP = (CPK + 31) / 32 * 32;
   constexpr int QB = 32;
   constexpr int PQ = lds_pitch<T>(CP);
@@ -897,7 +879,7 @@ template <typename T, int CPK, int NW> static size_t attn_smem(int which, int S)
   size_t b = carve_bytes(NW * 32, 4);
   b += which != K_DKV ? 2 * carve_bytes((S + 63) & ~63, 4) : carve_bytes((S + 31) & ~31, 4);
   if (which == K_FWD) b += 2 * carve_bytes(KB * PQ, e) + carve_bytes(NW * 32 * PQ, e);
-  else if (which == K_DQ) b += 2 * carve_bytes(KB * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e);
+  else if (which == K_DQ) b += 2 * carve_bytes(KB * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + carve_bytes(NW * 32, 4);
   else b += 2 * carve_bytes(32 * PQ, e) + 2 * carve_bytes(NW * 32 * PQ, e) + carve_bytes(64, 4);
   return b;
 }
@@ -979,27 +961,7 @@ extern "C" int cvh_attn_bwd_drop(int dtype, const void* qkv, const void* out, co
   AttnParams p = make_params(qkv, nullptr, dout, dqkv, const_cast<float*>(lse), dsum, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
   p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
   hipStream_t st = (hipStream_t)stream;
-  {
-    size_t total = (size_t)nseq * h * S;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    const int vec = (c % 4 == 0) ? 4 : ((c % 2 == 0) ? 2 : 1);
-    if (vec == 4 && h <= 64) {
-      const size_t ntok = (size_t)nseq * S;
-      int gr = (int)((ntok + 7) / 8);
-      if (gr > 8192) gr = 8192;
-      if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((attn_bwd_prep_rows_kernel<bf16_t>), dim3(gr), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, p);
-      else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((attn_bwd_prep_rows_kernel<float>), dim3(gr), dim3(256), 0, st, (const float*)out, (const float*)dout, p);
-      else return -1;
-    } else {
-#define PREP(TT, VV) hipLaunchKernelGGL((attn_bwd_prep_kernel<TT, VV>), dim3(g), dim3(256), 0, st, (const TT*)out, (const TT*)dout, p)
-    if (dtype == CVH_DT_BF16) { if (vec == 4) PREP(bf16_t, 4); else if (vec == 2) PREP(bf16_t, 2); else PREP(bf16_t, 1); }
-    else if (dtype == CVH_DT_F32) { if (vec == 4) PREP(float, 4); else if (vec == 2) PREP(float, 2); else PREP(float, 1); }
-    else return -1;
-#undef PREP
-    }
-    CVH_CHECK_LAUNCH();
-  }
+  p.out = const_cast<void*>(out);  // the dQ kernel forms D = rowsum(dO * O) itself
   int rc = dispatch_attn(dtype, K_DQ, p, st);
   if (rc) return rc;
   return dispatch_attn(dtype, K_DKV, p, st);

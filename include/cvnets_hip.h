@@ -69,6 +69,18 @@ int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2,
                   const void* residual, float drop_p, const unsigned long long* seed, unsigned int stream_id,
                   float* stats_part, void* stream);
 int cvh_conv_gemm_grid_rows(int M, int N);
+/* ---- the stem: 3x3 stride-2 pad-1 conv of the 3-channel NCHW image batch (fp32 or bf16) into Cout = 16 / 32 NHWC bf16 channels ----
+ * Replaces, for MobileViT's conv_1 (cvnets/models/classification/mobilevit.py:62-72; ConvLayer2d.forward, cvnets/layers/conv_layer.py:254-255),
+ * the NCHW -> NHWC(8) repack + the K = 72 implicit GEMM of the generic path: the image planes are read once, straight from NCHW.
+ * y is the raw conv output (BatchNorm follows through stats_part [cvh_stem_rows][2][Cout] = per-workgroup (sum, sum of squares) of the
+ * stored values, or NULL).  weight = torch layout [Cout][3][3][3] in w_dtype.  Needs W % 4 == 0; returns -2 for shapes it does not cover. */
+int cvh_stem_rows(int B, int H, int W, int Cout);
+int cvh_stem_conv_fwd(int in_dtype, const void* x_nchw, int w_dtype, const void* weight, void* y_bf16, float* stats_part, int B, int H, int W,
+                      int Cout, void* stream);
+/* weight-gradient partials of the same conv: part[cvh_stem_rows][Cout][9][8] float32 (the [N][KH*KW][pad8(Cin)] layout of cvh_gemm_dw's
+ * scratch; channels 3..7 are zero), summed by cvh_reduce_multi (kind 1) into the torch-layout gradient.  The image has no gradient. */
+int cvh_stem_conv_dw(int in_dtype, const void* x_nchw, const void* dy_bf16, float* part, int B, int H, int W, int Cout, void* stream);
+
 /* measurement aid (bench.py): launches since the last reset and the sum of their algorithmic bytes (input tensor(s) + output + every [M][N]
  * epilogue operand) of the two GEMM kernel families: out[0..1] = gemm_stream_kernel, out[2..3] = conv_gemm_kernel; out = long long[4];
  * reset != 0 clears the tallies */

@@ -32,6 +32,9 @@ SIGNATURES = {
     "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
     "cvh_conv_gemm_grid_rows": [I, I],
     "cvh_stream_counters": [I, P],  # out = long long[4]
+    "cvh_stem_rows": [I, I, I, I],
+    "cvh_stem_conv_fwd": [I, P, I, P, P, P, I, I, I, I, P],
+    "cvh_stem_conv_dw": [I, P, P, P, I, I, I, I, P],
     "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
     "cvh_gemm_dw_bias": [I, P, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
     "cvh_gemm_dw_folds_bias": [I, I, I, I],

@@ -218,10 +218,13 @@ def _conv_geometry(conv: nn.Conv2d) -> Tuple[int, int, int]:
 
 def _conv_forward(conv: nn.Conv2d, norm: Optional[nn.Module], act: Optional[nn.Module], x: Tensor, training: bool,
                   residual: Optional[Tensor] = None, x2: Optional[Tensor] = None) -> Tensor:
-    x = ops.to_nhwc(x)
     stride, pad, dil = _conv_geometry(conv)
     a = act_code(act)
     use_bn = norm is not None
+    stem = conv.groups == 1 and isinstance(norm, nn.BatchNorm2d) and ops.stem_eligible(x, conv.weight, conv.bias, stride, pad, dil, use_bn,
+                                                                                        residual, x2)
+    if not stem:
+        x = ops.to_nhwc(x)
     g = be = rm = rv = None
     momentum, eps, bn_training = 0.1, 1e-5, training
     if use_bn:
@@ -232,6 +235,8 @@ def _conv_forward(conv: nn.Conv2d, norm: Optional[nn.Module], act: Optional[nn.M
         bn_training = norm.training or not norm.track_running_stats
         if norm.training and norm.track_running_stats and not ops.bn_counters_bumped():
             norm.num_batches_tracked.add_(1)  # plumbing (scalar counter)
+    if stem:  # the raw NCHW image batch into the first conv: planes read once, no NHWC repack (csrc/stem.hip)
+        return ops.stem_conv_bn_act(x, conv.weight, g, be, rm, rv, act=a, training=bn_training, momentum=momentum, eps=eps)
     if conv.groups == 1:
         return ops.conv_bn_act(x, conv.weight, conv.bias, g, be, rm, rv, stride=stride, pad=pad, dil=dil, act=a, use_bn=use_bn,
                                training=bn_training, momentum=momentum, eps=eps, residual=residual, x2=x2)

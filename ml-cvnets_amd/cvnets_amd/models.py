@@ -70,6 +70,8 @@ def _encoder_prologue(self, x):
     if self.training:
         ops.advance_dropout_seed(x.device)
         ops.bump_bn_counters(self)
+    if x.dim() == 4 and x.shape[1] == 3 and not ops.is_nhwc(x):
+        return x  # the raw NCHW image batch goes to conv_1 as it is: the stem kernels read the planes directly (layers._conv_forward)
     return ops.to_nhwc(x)
 
 

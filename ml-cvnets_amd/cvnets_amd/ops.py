@@ -684,6 +684,73 @@ def conv_bn_act(x, weight, bias=None, gamma=None, beta=None, rmean=None, rvar=No
 
 
 # ------------------------------------------------------------------------------------------------
+# the stem: 3x3 stride-2 conv of the NCHW image batch (+BatchNorm +activation), image planes read once
+# ------------------------------------------------------------------------------------------------
+def stem_eligible(x, weight, bias, stride, pad, dil, use_bn, residual=None, x2=None) -> bool:
+    """conv_1 of MobileViT (cvnets/models/classification/mobilevit.py:62-72) fed with the raw NCHW batch: 3 -> 16 / 32 channels, 3x3,
+    stride 2, pad 1, BatchNorm behind it, bf16 compute, no gradient wanted for the image."""
+    return (_STEM_KERNEL and use_bn and bias is None and residual is None and x2 is None and x.dim() == 4 and x.shape[1] == 3
+            and tuple(weight.shape[1:]) == (3, 3, 3) and weight.shape[0] in (16, 32) and (stride, pad, dil) == (2, 1, 1)
+            and x.shape[3] % 4 == 0 and x.shape[2] >= 2 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
+            and not x.requires_grad and compute_dtype() == torch.bfloat16 and weight.dtype in (torch.float32, torch.bfloat16))
+
+
+_STEM_KERNEL = os.environ.get("CVH_STEM_KERNEL", "1") != "0"
+
+
+class StemConvBNAct(torch.autograd.Function):
+    """ConvLayer2d.forward (cvnets/layers/conv_layer.py:254-255) for the stem; x stays NCHW and is never repacked."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, rmean, rvar, cfg):
+        act, training, momentum, eps = cfg
+        _check_dev(x)
+        B, _, H, W = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        M = B * Ho * Wo
+        dev, dtype = x.device, torch.bfloat16
+        y = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        part, R = None, 0
+        if training:
+            R = _lib.query("cvh_stem_rows", B, H, W, Cout)
+            part = _f32(R * 2 * Cout, dev)
+        _lib.call("cvh_stem_conv_fwd", _dt(x), _p(x), _dt(weight), _p(weight), _p(y), _p(part), B, H, W, Cout, _stream())
+        stats = _bn_forward(y, M, Cout, part, R, gamma, beta, rmean, rvar, training, momentum, eps)
+        out = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
+        _lib.call("cvh_bn_apply", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, None, _p(out), M, Cout, _stream())
+        ctx.cfg = cfg
+        ctx.beta = beta
+        ctx.save_for_backward(x, weight, y, stats, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        act, training, momentum, eps = ctx.cfg
+        x, weight, y, stats, gamma = ctx.saved_tensors
+        B, _, H, W = x.shape
+        Cout = weight.shape[0]
+        M = y.shape[0] * y.shape[2] * y.shape[3]
+        dout = as_nhwc(dout)
+        dy, dgamma, dbeta = _bn_backward(y, dout, stats, gamma, act, M, Cout, training, beta=ctx.beta)
+        R = _lib.query("cvh_stem_rows", B, H, W, Cout)
+        part = _f32(R * Cout * 72, dy.device)
+        _lib.call("cvh_stem_conv_dw", _dt(x), _p(x), _p(dy), _p(part), B, H, W, Cout, _stream())
+        sink = _grad_sink(weight)
+        kw = dict(kind=1, N=Cout, Ktot=72, Cin=8, Cin_real=3, khw=9)
+        if sink is not None and defer_reduce(part, sink, R, Cout * 72, Cout * 72, **kw):
+            return None, None, dgamma, dbeta, None, None, None
+        dw = sink if sink is not None else torch.zeros(weight.shape, dtype=torch.float32, device=dy.device)
+        desc = _lib.ReduceDesc(part.data_ptr(), dw.data_ptr(), Cout * 72, Cout * 72, R, 1, Cout, 72, 8, 3, 9, 1.0, 1, 0)
+        _lib.call("cvh_reduce_multi", (_lib.ReduceDesc * 1)(desc), 1, _stream())
+        return None, (None if sink is not None else dw), dgamma, dbeta, None, None, None
+
+
+def stem_conv_bn_act(x, weight, gamma, beta, rmean, rvar, *, act=ACT_NONE, training=True, momentum=0.1, eps=1e-5):
+    return StemConvBNAct.apply(x, weight, gamma, beta, rmean, rvar, (int(act), bool(training), float(momentum), float(eps)))
+
+
+# ------------------------------------------------------------------------------------------------
 # depthwise conv (+BatchNorm +activation)
 # ------------------------------------------------------------------------------------------------
 class DWConvBNAct(torch.autograd.Function):

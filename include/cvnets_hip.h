@@ -85,6 +85,10 @@ int cvh_stem_conv_dw(int in_dtype, const void* x_nchw, const void* dy_bf16, floa
  * epilogue operand) of the two GEMM kernel families: out[0..1] = gemm_stream_kernel, out[2..3] = conv_gemm_kernel; out = long long[4];
  * reset != 0 clears the tallies */
 int cvh_stream_counters(int reset, long long* out);
+/* scratch floats cvh_gemm_dw / cvh_gemm_dw_bias want for a convolution geometry (a multiple of N * KH*KW*(C1+C2): the number of partial rows
+ * the chosen kernel writes).  Equals cvh_gemm_dw_scratch_elems(M, N, K) except for the 3x3 stride-1 convs of the MobileViT blocks. */
+long long cvh_gemm_dw_scratch_elems_conv(int dtype, int B, int H, int W, int Ho, int Wo, int C1, int C2, int KH, int KW, int stride, int pad,
+                                         int dil, int N, int with_bias);
 /* dW[N][Cin_real][KH][KW] (float32, torch layout) = (accumulate ? dW : 0) + dY[M][N]^T x im2col(src)[M][K].  The M range is split
  * over workgroups; with `scratch` (>= cvh_gemm_dw_scratch_elems(M, N, K) floats) every split stores its partial tile and a second
  * kernel sums them (no atomics); with scratch == NULL the splits add into dW with fp32 atomics (accumulate must be 1 and dW zeroed /

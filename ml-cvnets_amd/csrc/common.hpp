@@ -364,6 +364,7 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_NO_WAVE_PRIVATE 11 /* 1: single-K-step BatchNorm-link GEMMs keep the cooperative (barrier) staging */
 #define CVH_TUNE_NO_STREAM_GEMM 13 /* 1: short-K pointwise GEMMs stay on conv_gemm / gemm_nt128 instead of gemm_stream_kernel */
 #define CVH_TUNE_NO_CONV3X3 14 /* 1: dense 3x3 convolutions stay on the im2col conv_gemm_kernel instead of conv3x3_kernel */
+#define CVH_TUNE_NO_CONV3X3_DW 15 /* 1: the weight gradient of those convolutions stays on the im2col gemm_tn_kernel instead of conv3x3_dw_kernel */
 #define CVH_TUNE_MAX 16
 int cvh_tune_get(int key);
 

@@ -244,9 +244,38 @@ extern "C" int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot) {
 static int gemm_dw_finish(const GemmTNParams& p, int splits, int N, int KH, int KW, int C1, int C2, int Cin_real, float* dw, int accumulate,
                           hipStream_t st);
 
+// Scratch size of cvh_gemm_dw / cvh_gemm_dw_bias for a CONVOLUTION geometry: the 3x3 stride-1 convs of the MobileViT blocks go through
+// conv3x3_dw_kernel (conv3x3_dw.hip), which writes its own number of partial rows; everything else is cvh_gemm_dw_scratch_elems.
+extern "C" long long cvh_gemm_dw_scratch_elems_conv(int dtype, int B, int H, int W, int Ho, int Wo, int C1, int C2, int KH, int KW, int stride,
+                                                    int pad, int dil, int N, int with_bias) {
+  GemmTNParams p;
+  p.dy = nullptr; p.src1 = nullptr; p.src2 = C2 ? reinterpret_cast<const void*>(1) : nullptr; p.C1 = C1; p.C2 = C2; p.dw = nullptr;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.M = B * Ho * Wo; p.N = N; p.Ktot = KH * KW * (C1 + C2); p.Cin_real = C1 + C2;
+  p.dy_xf = make_xf(nullptr); p.x_xf = make_xf(nullptr);
+  p.bias_part = with_bias ? reinterpret_cast<float*>(1) : nullptr; p.part = nullptr;
+  if (dtype == CVH_DT_BF16 && conv3x3_dw_eligible(p)) return (long long)conv3x3_dw_rows(p) * N * p.Ktot;
+  return cvh_gemm_dw_scratch_elems(p.M, N, p.Ktot);
+}
+
 static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1, int C2, int Cin_real, float* dw, float* scratch,
                        long long scratch_elems, int accumulate, hipStream_t st, bool fx) {
   if (p.M <= 0) return 0;
+  if (!fx && dtype == CVH_DT_BF16 && scratch != nullptr && conv3x3_dw_eligible(p)) {  // 3x3 convs of the MobileViT blocks: halo tile in LDS, X read once
+    const int rows3 = conv3x3_dw_rows(p);
+    const long long row_elems = (long long)N * p.Ktot;
+    if (scratch_elems >= rows3 * row_elems) {
+      p.part = scratch;
+      const int rc = launch_conv3x3_dw(p, st);
+      if (rc) return rc;
+      const long long have = scratch_elems / row_elems;  // a caller that sized the scratch with the generic query sums `have` rows
+      if (dw == nullptr && have > rows3) {
+        hipError_t e = hipMemsetAsync(scratch + rows3 * row_elems, 0, (size_t)(have - rows3) * row_elems * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+      }
+      return gemm_dw_finish(p, rows3, N, KH, KW, C1, C2, Cin_real, dw, accumulate, st);
+    }
+  }
   int out_tiles, splits, mps;
   tn_plan(p.M, N, p.Ktot, &out_tiles, &p.k_tiles, &splits, &mps);
   p.m_per_split = mps;

@@ -65,5 +65,9 @@ int launch_gemm_stream(const ConvGemmParams& p, hipStream_t st);
 // conv3x3.hip
 bool conv3x3_eligible(const ConvGemmParams& p);
 int launch_conv3x3(const ConvGemmParams& p, int rows, hipStream_t st);
+// conv3x3_dw.hip
+bool conv3x3_dw_eligible(const GemmTNParams& p);
+int conv3x3_dw_rows(const GemmTNParams& p);
+int launch_conv3x3_dw(const GemmTNParams& p, hipStream_t st);
 bool gemm_stream_fx_eligible(const ConvGemmParams& p);
 int launch_gemm_stream_fx(const ConvGemmParams& p, int rows, hipStream_t st);

@@ -81,11 +81,9 @@ template <typename TI, int NB>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   constexpr int NOUT = 16 * NB;
   __shared__ __attribute__((aligned(16))) bf16_t xt[ST_XT];
-  __shared__ float red[2 * NOUT];
+  __shared__ float red[4][2 * NOUT];  // per-wave column sums, added in wave order: the statistics are bit-reproducible run to run
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   for (int i = tid; i < ST_XT / 8; i += 256) reinterpret_cast<uint4*>(xt)[i] = make_uint4(0, 0, 0, 0);
-  if (tid < 2 * NOUT) red[tid] = 0.f;
-
   // weight fragments: lane (channel l15, k group g); k = 8g + j <-> (kh = g >> 1, slot = 2*(g & 1) + (j >> 2), c = j & 3); second k-step: kh = 2
   bf16x8_t wa[NB][2];
 #pragma unroll
@@ -166,12 +164,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
           q += __shfl_xor(q, m, 64);
         }
         if (l15 == 0) {
-          atomicAdd(&red[nb * 16 + 4 * g + e], a);
-          atomicAdd(&red[NOUT + nb * 16 + 4 * g + e], q);
+          red[wave][nb * 16 + 4 * g + e] = a;
+          red[wave][NOUT + nb * 16 + 4 * g + e] = q;
         }
       }
     __syncthreads();
-    if (tid < 2 * NOUT) p.stats_part[(size_t)blockIdx.x * 2 * NOUT + tid] = red[tid];
+    if (tid < 2 * NOUT) p.stats_part[(size_t)blockIdx.x * 2 * NOUT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 
@@ -247,14 +245,18 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(StemParams p) {
   }
 
   // acc[nb][kh][e]: n = nb*16 + 4g + e, column l15 = (slot, c)
+  // the four waves add their accumulators one after the other (fixed order: the partial row is bit-reproducible)
   const int slot = l15 >> 2, c = l15 & 3;
-  if (slot < 3 && c < 3) {
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w && slot < 3 && c < 3) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(&red[((nb * 16 + 4 * g + e) * 9 + kh * 3 + slot) * 8 + c], acc[nb][kh][e]);
+          for (int e = 0; e < 4; ++e) red[((nb * 16 + 4 * g + e) * 9 + kh * 3 + slot) * 8 + c] += acc[nb][kh][e];
+    }
   }
   __syncthreads();
   for (int i = tid; i < NOUT * 72; i += 256) p.part[(size_t)blockIdx.x * NOUT * 72 + i] = red[i];

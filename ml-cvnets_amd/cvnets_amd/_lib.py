@@ -39,6 +39,7 @@ SIGNATURES = {
     "cvh_gemm_dw_bias": [I, P, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
     "cvh_gemm_dw_folds_bias": [I, I, I, I],
     "cvh_gemm_dw_scratch_elems": [I, I, I],
+    "cvh_gemm_dw_scratch_elems_conv": [I, I, I, I, I, I, I, I, I, I, I, I, I, I, I],
     "cvh_dwconv_fwd": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "cvh_dwconv_rows": [I, I, I, I, I, I, I, I],
     "cvh_dwconv_bwd_x": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
@@ -149,7 +150,7 @@ def load():
                 continue
             raise
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name.endswith("_elems") else c_int
+        fn.restype = c_longlong if "_elems" in name else c_int
     for kv in filter(None, os.environ.get("CVH_TUNE", "").split(",")):  # developer A/B knob overrides, e.g. CVH_TUNE="6=512,2=1024"
         k, v = kv.split("=")
         lib.cvh_set_tuning(int(k), int(v))

@@ -518,7 +518,8 @@ def _weight_grad(dy, x, x2, C1, C2, weight, B, H, W, Ho, Wo, KH, KW, stride, pad
     sink = _grad_sink(weight)
     Ktot = KH * KW * (C1 + C2)
     M = B * Ho * Wo
-    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", M, N, Ktot)
+    n_scr = _lib.query("cvh_gemm_dw_scratch_elems_conv", _dt(dy), B, H, W, Ho, Wo, C1, C2, KH, KW, stride, pad, dil, N,
+                       1 if bias_sink is not None else 0)
     if sink is not None:
         # in-place parameter gradients: split partials now, their sum at the end of backward (cvh_reduce_multi) — or right here when deferral is
         # off; on the parameter-gradient side stream when that is enabled (CVH_ASYNC_DW=1), else on the current stream

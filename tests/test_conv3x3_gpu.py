@@ -77,3 +77,47 @@ def test_conv3x3_input_gradient_of_two_source_conv():
     ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w.bfloat16().float(), padding=1).permute(0, 2, 3, 1)
     got = torch.cat([dx1, dx2], dim=3).float()
     assert float((got - ref).abs().max() / ref.abs().max()) < 8e-3
+
+
+DW_CASES = [
+    # B, H, W, C1, C2, N
+    (16, 32, 32, 96, 0, 96), (16, 32, 32, 96, 96, 96), (64, 16, 16, 128, 0, 128), (64, 16, 16, 128, 128, 128), (256, 8, 8, 160, 160, 160),
+    (40, 20, 24, 96, 0, 96), (20, 33, 31, 128, 96, 128), (16, 32, 32, 48, 0, 96), (16, 32, 32, 64, 208, 96), (300, 8, 8, 160, 0, 160),
+]
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,N", DW_CASES)
+def test_conv3x3_weight_gradient_matches_torch_and_im2col_kernel(B, H, W, C1, C2, N):
+    """conv3x3_dw_kernel (csrc/conv3x3_dw.hip) through cvh_gemm_dw: against torch's conv weight gradient in fp32 on the same bf16 operands
+    (fp32 accumulation of bf16 products: 2e-3 of the magnitude) and against the im2col dW kernel (CVH_TUNE key 15 switches the new one off)"""
+    from cvnets_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(B + H + C1 + N)
+    x = torch.randn(B, H, W, C1, device=DEV, generator=g).bfloat16()
+    x2 = torch.randn(B, H, W, C2, device=DEV, generator=g).bfloat16() if C2 else None
+    dy = torch.randn(B, H, W, N, device=DEV, generator=g).bfloat16()
+    Cin = C1 + C2
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        n_scr = _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, B, H, W, H, W, C1, C2, 3, 3, 1, 1, 1, N, 0)
+        scr = torch.full((max(n_scr, 1),), float("nan"), device=DEV)
+        dw = torch.full((N, Cin, 3, 3), float("nan"), device=DEV)
+        _lib.call("cvh_gemm_dw", 1, dy.data_ptr(), x.data_ptr(), x2.data_ptr() if C2 else None, C1, C2, dw.data_ptr(), B, H, W, H, W, 3, 3, 1, 1, 1,
+                  N, Cin, scr.data_ptr(), n_scr, 0, s)
+        torch.cuda.synchronize()
+        return dw, n_scr
+
+    dw, n_new = run()
+    _lib.call("cvh_set_tuning", 15, 1)
+    try:
+        dw_old, n_old = run()
+    finally:
+        _lib.call("cvh_set_tuning", 15, 0)
+    assert n_new % (N * 9 * Cin) == 0 and n_old % (N * 9 * Cin) == 0
+    xin = x if x2 is None else torch.cat([x, x2], dim=3)
+    w = torch.zeros(N, Cin, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(xin.float().permute(0, 3, 1, 2), w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    scale = float(w.grad.abs().max())
+    assert not torch.isnan(dw).any()
+    assert float((dw - w.grad).abs().max()) / scale < 2e-3
+    assert float((dw - dw_old).abs().max()) / scale < 2e-3

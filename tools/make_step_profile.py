@@ -4,7 +4,7 @@ command itself (read by bench.py for `roofline.traffic` and `roofline.dominant_k
 
     python tools/make_step_profile.py <kernel-trace dir> <pmc FETCH_SIZE dir> <pmc WRITE_SIZE dir> <batch> <tag> > profiles/step_profile.json
 
-* kernel trace (`rocprofv3 --kernel-trace --stats`): the last full step (between two nchw_to_nhwc launches): launches, total and average
+* kernel trace (`rocprofv3 --kernel-trace --stats`): the last full step (between two launches of the step's first kernel: stem_fwd_kernel, or nchw_to_nhwc on builds without it): launches, total and average
   duration per kernel family (symbol name up to its template arguments), share of the summed kernel time, the DOMINANT family = largest share;
 * PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs): HBM bytes per step and per family — FETCH_SIZE doubled (gfx950: 128-B
   requests tallied at 64 B, MI355X_MICROARCH.md), WRITE_SIZE as exported;
@@ -50,7 +50,7 @@ def counter(d, cname):
 def main():
     trace, d_f, d_w, batch, tag = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     rows = sorted(csv.DictReader(open(glob.glob(f"{trace}/**/*kernel_trace.csv", recursive=True)[0])), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if ("stem_fwd_kernel" in r["Kernel_Name"] or "nchw_to_nhwc" in r["Kernel_Name"])]
     step = rows[idx[-2]:idx[-1]]
     window_ms = (int(rows[idx[-1]]["Start_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e6
     fam = collections.OrderedDict()
@@ -61,7 +61,7 @@ def main():
     total_ms = sum(f["ms"] for f in fam.values())
     fetch, cnt = counter(d_f, "FETCH_SIZE")
     write, _ = counter(d_w, "WRITE_SIZE")
-    steps = max(1, cnt.get("nchw_to_nhwc_kernel", 1))
+    steps = max(1, sum(v for k, v in cnt.items() if "stem_fwd_kernel" in k or "nchw_to_nhwc" in k) or 1)
     out_f = []
     for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
         b = (2.0 * fetch.get(name, 0.0) + write.get(name, 0.0)) / steps

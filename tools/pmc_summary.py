@@ -8,7 +8,7 @@
 
 Units / corrections (guide, HBM section): both counters are in KiB-sized units of 64-B fabric requests as exported by rocprofv3
 (value x 1024 = bytes); on gfx950 FETCH_SIZE tallies the 128-B requests of wide streaming reads at 64 B, so it is DOUBLED here;
-WRITE_SIZE is taken as is (uncalibrated — treat as a lower bound).  Steps = number of nchw_to_nhwc dispatches (one per step)."""
+WRITE_SIZE is taken as is (uncalibrated — treat as a lower bound).  Steps = number of stem_fwd_kernel (older builds: nchw_to_nhwc) dispatches (one per step)."""
 import collections
 import csv
 import glob
@@ -30,7 +30,7 @@ def load(d, counter):
 
 fetch, cnt = load(sys.argv[1], "FETCH_SIZE")
 write, _ = load(sys.argv[2], "WRITE_SIZE")
-steps = max(1, sum(v for k, v in cnt.items() if "nchw_to_nhwc" in k))
+steps = max(1, sum(v for k, v in cnt.items() if "stem_fwd_kernel" in k or "nchw_to_nhwc" in k))
 tf, tw = 2.0 * sum(fetch.values()), sum(write.values())
 print(f"steps profiled: {steps};  HBM traffic per step: read {tf / steps / 1e9:.1f} GB (FETCH_SIZE x2)  write {tw / steps / 1e9:.1f} GB  total {(tf + tw) / steps / 1e9:.1f} GB")
 print(f"{'kernel':54s} {'launches/step':>13s} {'read MB/launch':>15s} {'write MB/launch':>16s} {'GB/step':>8s}")

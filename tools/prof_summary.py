@@ -3,7 +3,7 @@ d=sys.argv[1]
 import glob
 rows=list(csv.DictReader(open(glob.glob(f'{d}/*kernel_trace.csv')[0])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'stem_fwd_kernel' in r['Kernel_Name'] or 'nchw_to_nhwc' in r['Kernel_Name']]
 step=rows[idx[-2]:idx[-1]]
 tot=sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in step)
 print(len(step),'kernels', tot/1e6,'ms/step')

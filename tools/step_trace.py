@@ -1,7 +1,7 @@
 """Ordered launch list of the last full training step in a rocprofv3 kernel trace: one line per launch with its start offset in
 the step, duration, grid, registers, LDS and stream — the table the per-layer kernel work is planned from.
 
-usage: python tools/step_trace.py <rocprof dir> [step marker kernel substring, default nchw_to_nhwc]"""
+usage: python tools/step_trace.py <rocprof dir> [step marker kernel substring, default stem_fwd_kernel]"""
 import csv
 import glob
 import re
@@ -15,7 +15,7 @@ def short(n):
 
 def main():
     f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-    marker = sys.argv[2] if len(sys.argv) > 2 else "nchw_to_nhwc"
+    marker = sys.argv[2] if len(sys.argv) > 2 else "stem_fwd_kernel"
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     step = rows[idx[-2]:idx[-1]]

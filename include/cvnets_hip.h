@@ -190,6 +190,13 @@ int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand_xf* dy_xf,
  *        matrix G = x^T x [pad8(K)][pad8(K)] (cvh_gemm_dw on x, x) and the column sums s[pad8(K)] (cvh_colsum) into dw[N][K].
  * w = float32 [N][K] (torch [N][K][1][1]).  y itself is never read.  Replaces Conv2d(1x1).backward behind a BatchNorm. */
 int cvh_bn_dx_weights(int dtype, const float* w, const float* coef, void* wcat, float* bias, int N, int K, void* stream);
+/* dX (as above: [g | x] wcat^T + bias (+ residual)) AND the raw product P = g^T x of dW from ONE pass over g [M][hid] (bf16; the 4x-wide
+ * gradient is streamed once instead of once per product): p_part[cvh_ir_exp_bwd_rows][hid][Cin] float32 partial products, summed with
+ * cvh_sum_partials and finished by cvh_bn_dw_combine.  Covers (hid, Cin) = (64, 16), (128, 32), (256, 64) with M >= 65536 — the expansion
+ * convs of MobileViT's layer_1 .. layer_3 (cvnets/modules/mobilenetv2.py:180-193); cvh_ir_exp_bwd_rows returns 0 for anything else. */
+int cvh_ir_exp_bwd_rows(long long M, int hid, int Cin);
+int cvh_ir_exp_bwd(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
+                   float* p_part, long long M, int hid, int Cin, void* stream);
 int cvh_bn_dw_combine(const float* P, const float* w, const float* G, const float* s, const float* coef, float* dw, int N, int K,
                       int accumulate, void* stream);
 

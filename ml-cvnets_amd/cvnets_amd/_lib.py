@@ -33,6 +33,8 @@ SIGNATURES = {
     "cvh_conv_gemm_grid_rows": [I, I],
     "cvh_stream_counters": [I, P],  # out = long long[4]
     "cvh_stem_rows": [I, I, I, I],
+    "cvh_ir_exp_bwd_rows": [L, I, I],
+    "cvh_ir_exp_bwd": [I, P, P, P, P, P, P, P, L, I, I, P],
     "cvh_stem_conv_fwd": [I, P, I, P, P, P, I, I, I, I, P],
     "cvh_stem_conv_dw": [I, P, P, P, I, I, I, I, P],
     "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],

@@ -22,6 +22,7 @@ import torch
 from . import _lib, ops
 from .ops import ACT_NONE, _dt, _f32, _p, _stream
 
+_IR_EXP_FUSED = __import__("os").environ.get("CVH_IR_EXP_FUSED", "1") != "0"
 DW_SHAPE_LOG = None  # set to a list to record the plain dW GEMMs launched from this module (bench.py)
 
 
@@ -86,7 +87,7 @@ def _pw_weight_grad(dy, dy_xf_args, x, x_xf_args, weight, M, N, K):
     return dw
 
 
-def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp):
+def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp, P_ready=None):
     """dW of a 1x1 conv y = x W^T that sits in front of a train-mode BatchNorm, from g = dz * act'(bn(y)) and the backward coefficients
     coef[3][N] of that BatchNorm:  dW = diag(ca) (g^T x) + diag(cb) W (x^T x) + cc (1^T x)  — y is not read (csrc/bnlink.hip)."""
     sink = ops._grad_sink(weight)
@@ -103,7 +104,7 @@ def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp):
             _lib.call("cvh_gemm_dw", _dt(dy), _p(dy), _p(x), None, Kp, 0, _p(out), int(M), 1, 1, 1, 1, 1, 1, 1, 0, 1, int(n_cols), int(cin_real),
                       _p(scr), n_scr, 0, _stream())
             return out
-        P = gemm_dw(g, N, Kr)      # g^T x   [N][Kr]
+        P = P_ready if P_ready is not None else gemm_dw(g, N, Kr)      # g^T x   [N][Kr]
         G = gemm_dw(x, Kp, Kp)     # x^T x   [Kp][Kp]
         R = _lib.query("cvh_colreduce_rows", int(M), int(Kp))
         part = _f32(R * 2 * Kp, dev)
@@ -111,7 +112,7 @@ def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp):
         _lib.call("cvh_colsum", _dt(x), _p(x), int(M), int(Kp), _p(part), _p(s_), 1.0, 0, _stream())
         _lib.call("cvh_bn_dw_combine", _p(P), _p(weight), _p(G), _p(s_), _p(coef), _p(dw), int(N), int(Kr), accumulate, _stream())
 
-    side = ops._param_grad_stream(dev) if sink is not None else None
+    side = ops._param_grad_stream(dev) if (sink is not None and P_ready is None) else None
     if side is not None:
         with torch.cuda.stream(side):
             for t in (g, x, coef):
@@ -206,16 +207,25 @@ class InvertedResidualFn(torch.autograd.Function):
                       1 if sink is not None else 0, _stream())
         # expansion conv (LINEAR in x): dy1 = ca*g1 + cb*y1 + cc is never formed and y1 is never re-read — dX1 is one plain GEMM over
         # the channel-concat [g1 | x] with a small derived weight, dW1 the plain dW GEMM on g1 plus K x K glue (csrc/bnlink.hip)
-        dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin)
         dx = None
+        P1 = None
         if ctx.needs_input_grad[0]:
             wcat = torch.empty(Cin * (hid + Cin), dtype=dt, device=dev)
             bias = _f32(Cin, dev)
             _lib.call("cvh_bn_dx_weights", _dt(g1t), _p(w1), _p(coef1), _p(wcat), _p(bias), hid, w1.shape[1], _stream())
             dx = ops.nhwc_empty(B, Cin, H, W, dt, dev)
-            ops._conv_gemm(g1t, x, hid, Cin, wcat, dx, M1, 1, 1, 1, 1, 1, 1, 1, 0, 1, Cin, bias=bias, residual=dout if use_res else None)
+            R1 = _lib.query("cvh_ir_exp_bwd_rows", M1, hid, Cin) if (_IR_EXP_FUSED and dt == torch.bfloat16 and w1.shape[1] == Cin) else 0
+            if R1 > 0:  # dX1 and the raw dW1 product g1^T x from ONE pass over g1 (csrc/ir_bwd.hip)
+                ppart = _f32(R1 * hid * Cin, dev)
+                _lib.call("cvh_ir_exp_bwd", _dt(g1t), _p(g1t), _p(x), _p(wcat), _p(bias), _p(dout if use_res else None), _p(dx), _p(ppart), M1,
+                          hid, Cin, _stream())
+                P1 = _f32(hid * Cin, dev)
+                _lib.call("cvh_sum_partials", _p(ppart), R1, hid * Cin, hid * Cin, _p(P1), 1.0, 0, _stream())
+            else:
+                ops._conv_gemm(g1t, x, hid, Cin, wcat, dx, M1, 1, 1, 1, 1, 1, 1, 1, 0, 1, Cin, bias=bias, residual=dout if use_res else None)
         elif use_res:
             dx = dout
+        dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin, P_ready=P1)
         return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None)
 
 

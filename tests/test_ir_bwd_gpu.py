@@ -1,0 +1,66 @@
+"""ir_exp_bwd_kernel (csrc/ir_bwd.hip): the input gradient and the raw weight-gradient product of an InvertedResidual expansion conv
+(cvnets/modules/mobilenetv2.py:180-193; nn.Conv2d 1x1 backward behind a BatchNorm, cvnets/layers/conv_layer.py:254-255) from one pass
+over the wide gradient, against fp32 matmuls on the same bf16 operands (dX: one bf16 rounding, 8e-3 of the magnitude; P: fp32
+accumulation of bf16 products, 2e-3), and through InvertedResidualFn against the two-kernel path (CVH_IR_EXP_FUSED off).
+Row counts are not multiples of the 64-row tile; with and without the residual gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("hid,Cin", [(64, 16), (128, 32), (256, 64)])
+@pytest.mark.parametrize("M,res", [(65536 + 37, True), (70001, False), (262144, True)])
+def test_ir_exp_bwd_matches_matmul(hid, Cin, M, res):
+    from cvnets_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(hid + M)
+    gt = torch.randn(M, hid, device=DEV, generator=g).bfloat16()
+    x = torch.randn(M, Cin, device=DEV, generator=g).bfloat16()
+    wcat = (torch.randn(Cin, hid + Cin, device=DEV, generator=g) * (hid + Cin) ** -0.5).bfloat16()
+    bias = torch.randn(Cin, device=DEV, generator=g)
+    r = torch.randn(M, Cin, device=DEV, generator=g).bfloat16() if res else None
+    R = _lib.query("cvh_ir_exp_bwd_rows", M, hid, Cin)
+    assert R > 0
+    dx = torch.full((M, Cin), float("nan"), device=DEV, dtype=torch.bfloat16)
+    part = torch.full((R, hid, Cin), float("nan"), device=DEV)
+    _lib.call("cvh_ir_exp_bwd", 1, gt.data_ptr(), x.data_ptr(), wcat.data_ptr(), bias.data_ptr(), r.data_ptr() if res else None, dx.data_ptr(),
+              part.data_ptr(), M, hid, Cin, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = torch.cat([gt.float(), x.float()], 1) @ wcat.float().t() + bias
+    if res:
+        ref = ref + r.float()
+    assert not torch.isnan(dx.float()).any()
+    assert float((dx.float() - ref).abs().max() / ref.abs().max()) < 8e-3
+    P = part.sum(0)
+    Pref = (gt.double().t() @ x.double()).float()
+    assert float((P - Pref).abs().max() / Pref.abs().max()) < 2e-3
+
+
+def test_inverted_residual_step_with_and_without_the_fused_expansion_backward():
+    from cvnets_amd import fused, layers, ops
+    from cvnets_amd.modules import InvertedResidual
+    opts = layers.default_opts()
+    x = (torch.randn(20, 64, 64, 64, device=DEV)).bfloat16().contiguous(memory_format=torch.channels_last)
+    go = None
+    res = {}
+    for on in (True, False):
+        torch.manual_seed(5)
+        m = InvertedResidual(opts, 64, 64, stride=1, expand_ratio=4).to(DEV).train()
+        xin = x.clone().requires_grad_(True)
+        fused._IR_EXP_FUSED = on
+        ops.set_compute_dtype(torch.bfloat16)
+        try:
+            out = m(xin)
+            if go is None:
+                go = torch.randn_like(out.float()).to(out.dtype)
+            out.backward(go)
+            ops.finish_backward()
+        finally:
+            fused._IR_EXP_FUSED = True
+            ops.set_compute_dtype(None)
+        torch.cuda.synchronize()
+        res[on] = [xin.grad.float()] + [p_.grad.float().clone() for p_ in m.parameters()]
+    for a, b in zip(res[True], res[False]):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) / scale < 2e-2, (a.shape, float((a - b).abs().max()), scale)

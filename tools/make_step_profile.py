@@ -33,7 +33,7 @@ def src_hash():
 
 
 def family(name):
-    n = re.sub(r"^void ", "", name)
+    n = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n)
     return re.sub(r"<.*", "", n)
 

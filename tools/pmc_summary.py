@@ -22,7 +22,7 @@ def load(d, counter):
     for r in rows:
         if r["Counter_Name"] != counter:
             continue
-        n = re.sub(r"\(.*", "", re.sub(r"^void ", "", r["Kernel_Name"]))[:52]
+        n = re.sub(r"\(.*", "", re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", ""))[:52]
         tot[n] += float(r["Counter_Value"]) * 1024.0
         cnt[n] += 1
     return tot, cnt

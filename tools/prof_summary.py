@@ -8,7 +8,7 @@ step=rows[idx[-2]:idx[-1]]
 tot=sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in step)
 print(len(step),'kernels', tot/1e6,'ms/step')
 def short(n):
-    n=re.sub(r"^void ","",n); return re.sub(r"\(.*","",n)[:48]
+    n=re.sub(r"^void ","",n).replace('(anonymous namespace)::',''); return re.sub(r"\(.*","",n)[:48]
 byname=collections.defaultdict(lambda:[0,0])
 agg=collections.defaultdict(lambda:[0,0])
 for r in step:

@@ -9,7 +9,7 @@ import sys
 
 
 def short(n):
-    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*", "", n)[:56]
 
 

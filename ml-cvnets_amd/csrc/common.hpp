@@ -329,6 +329,22 @@ __device__ __forceinline__ f32x16_t acc_zero() {
 // ds_read_b128 lane group land on distinct 4-bank slots (pitch/4 dwords odd multiple of 4).
 template <typename T> __host__ __device__ constexpr int lds_pitch(int k) { return k + 16 / (int)sizeof(T); }
 
+// Deterministic replacement for "every thread atomicAdd()s its partial sums into a small LDS array" at the end of a kernel: the threads
+// that share a destination take turns in a fixed order (turn 0 .. nturns-1, one workgroup barrier per turn; threads of one turn must hit
+// distinct addresses).  The order in which LDS float atomics retire differs from run to run; with the turns the kernel's statistics /
+// partial rows — and with them the whole training step — are bit-reproducible.  Call from workgroup-uniform control flow.
+template <typename F> __device__ __forceinline__ void lds_ordered_accumulate(int my_turn, int nturns, bool active, F&& add) {
+  for (int t = 0; t < nturns; ++t) {
+    if (active && my_turn == t) add();
+    __syncthreads();
+  }
+}
+// fixed-shape butterfly over the lanes l, l + stride, l + 2*stride, ... of a wave (stride a power of two): afterwards every lane holds the sum
+__device__ __forceinline__ float wave_strided_sum(float v, int stride) {
+  for (int m = stride; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
 // compile-time loop: body receives std::integral_constant<int, I> (keeps register arrays statically indexed)
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {

@@ -190,14 +190,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvGemmParams p, Conv3
   }
 
   if (want_stats) {
-    if (e_active) {
+    lds_ordered_accumulate(wave * ppl + e_px, 4 * ppl, e_active, [&]() {  // the lanes that own one 8-channel piece, in (wave, pixel slot) order
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        atomicAdd(&red[e_piece * 8 + j], cs1[j]);
-        atomicAdd(&red[N + e_piece * 8 + j], cs2[j]);
+        red[e_piece * 8 + j] += cs1[j];
+        red[N + e_piece * 8 + j] += cs2[j];
       }
-    }
-    __syncthreads();
+    });
     for (int i = tid; i < 2 * N; i += 256) {
       const int which = i / N, n = i - which * N;
       if (n < p.N) {

@@ -364,13 +364,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
       constexpr int g = decltype(gi)::value;
       constexpr int CH = SG::width[g] * 4;
       const int col = SG::start[g] * 32 + (lane % CH) * 8;
+      // lanes l, l + CH, ... of a wave own the same 8 columns: fixed butterfly inside the wave, then the 4 waves in order
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        atomicAdd(&red[col + j], cs1[g][j]);
-        atomicAdd(&red[BN + col + j], cs2[g][j]);
+        cs1[g][j] = wave_strided_sum(cs1[g][j], CH);
+        cs2[g][j] = wave_strided_sum(cs2[g][j], CH);
       }
+      lds_ordered_accumulate(tid >> 6, 4, lane < CH, [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          red[col + j] += cs1[g][j];
+          red[BN + col + j] += cs2[g][j];
+        }
+      });
     });
-    __syncthreads();
     for (int col = tid; col < BN; col += 256) {
       int n = n0 + col;
       if (n < p.N) {

@@ -194,12 +194,13 @@ __global__ __launch_bounds__(256, 2) void dwf_fwd_kernel(DwfParams p) {
   }
   if (want_stats) {
     __syncthreads();
+    lds_ordered_accumulate(pl, 32, true, [&]() {  // the 32 pixel lanes of a channel group, in order
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&red[cl * 8 + j], s1[j]);
-      atomicAdd(&red[DWF_CC + cl * 8 + j], s2[j]);
-    }
-    __syncthreads();
+      for (int j = 0; j < 8; ++j) {
+        red[cl * 8 + j] += s1[j];
+        red[DWF_CC + cl * 8 + j] += s2[j];
+      }
+    });
     for (int i = tid; i < 2 * DWF_CC; i += 256) {
       const int which = i / DWF_CC, c = c0 + (i - which * DWF_CC);
       if (c < p.C) p.stats_part[((size_t)row_id * 2 + which) * p.C + c] = red[i];
@@ -464,16 +465,17 @@ __global__ __launch_bounds__(256, 2) void dwf_bwd_kernel(DwfParams p) {
 
   // ---- workgroup totals: statistics and dW ----
   __syncthreads();
+  lds_ordered_accumulate(pl, 32, true, [&]() {  // the 32 pixel lanes of a channel group, in order
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    atomicAdd(&red[cl * 8 + j], s1[j]);
-    atomicAdd(&red[DWF_CC + cl * 8 + j], s2[j]);
-  }
+    for (int j = 0; j < 8; ++j) {
+      red[cl * 8 + j] += s1[j];
+      red[DWF_CC + cl * 8 + j] += s2[j];
+    }
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&dwl[t * DWF_CC + cl * 8 + j], dwa[t][j]);
-  __syncthreads();
+      for (int j = 0; j < 8; ++j) dwl[t * DWF_CC + cl * 8 + j] += dwa[t][j];
+  });
   for (int i = tid; i < 2 * DWF_CC; i += 256) {
     const int which = i / DWF_CC, c = c0 + (i - which * DWF_CC);
     if (c < p.C) p.stats_part[((size_t)row_id * 2 + which) * p.C + c] = red[i];

@@ -230,12 +230,19 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
     }
   }
   if (EM) {  // workgroup totals -> partial row xb of this column tile; the caller's surplus rows are zeroed
+    // lanes my_ch, my_ch + ppr, ... of a wave own the same 8 columns: fixed butterfly inside the wave, then the 16 waves in order
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(&red[my_ch * 8 + j], cs1[j]);
-      atomicAdd(&red[g.bn + my_ch * 8 + j], cs2[j]);
+      cs1[j] = wave_strided_sum(cs1[j], ppr);
+      cs2[j] = wave_strided_sum(cs2[j], ppr);
     }
-    __syncthreads();
+    lds_ordered_accumulate(wave, GS_WAVES, lane < ppr, [&]() {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[my_ch * 8 + j] += cs1[j];
+        red[g.bn + my_ch * 8 + j] += cs2[j];
+      }
+    });
     for (int i = tid; i < 2 * g.bn; i += 64 * GS_WAVES) {
       const int which = i / g.bn, n = n0 + (i - which * g.bn);
       if (n < N) {

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, 
                                                        float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C,
                                                        const T* __restrict__ dres /* optional: dx += dres (residual fork) */) {
   constexpr int RPW = 64 / G, U = 2;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C], zeroed, LDS atomics from every (wave, row group)
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C], zeroed; every (wave, row group) adds its sums in a fixed order
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gl = lane % G, gr = lane / G;
   const int c0 = gl * 8;
@@ -265,14 +265,13 @@ __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  if (cok) {
+  lds_ordered_accumulate(wave * RPW + gr, 4 * RPW, cok, [&]() {  // the (wave, row slot) owners of one 8-channel group, in order
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(&red[c0 + j], dg[j]);
-      atomicAdd(&red[C + c0 + j], db[j]);
+      red[c0 + j] += dg[j];
+      red[C + c0 + j] += db[j];
     }
-  }
-  __syncthreads();
+  });
   for (int i = threadIdx.x; i < 2 * C; i += 256) part[(size_t)blockIdx.x * 2 * C + i] = red[i];
 }
 

@@ -1,0 +1,39 @@
+"""The training step is bit-reproducible: two forward + backward passes of MobileViT-S (bf16, 256 x 256, train-mode BatchNorm, the fused
+InvertedResidual / attention / stem kernels of the benchmark configuration) from the same parameters and batch give IDENTICAL logits
+and gradients.  Every reduction inside the kernels runs in a fixed order (csrc/common.hpp: lds_ordered_accumulate, wave_strided_sum;
+split-M partial rows summed by cvh_reduce_multi's fixed tree) — there is no float atomic on the path.  Dropout is off here only because
+its counter-based masks advance with every forward (cvnets_amd.ops.advance_dropout_seed), as torch's generator would."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_steps_from_the_same_state_are_bit_identical():
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+
+    opts = default_opts(**{"model.classification.mit.mode": "small", "model.classification.mit.dropout": 0.0,
+                           "model.classification.classifier_dropout": 0.0})
+    torch.manual_seed(0)
+    model = cvnets_amd.MobileViT(opts).cuda().train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(24, 3, 256, 256, device="cuda")
+    y = torch.randint(0, 1000, (24,), device="cuda")
+    cvnets_amd.set_compute_dtype(torch.bfloat16)
+    runs = []
+    try:
+        for _ in range(2):
+            model.load_state_dict(state)
+            model.zero_grad(set_to_none=True)
+            logits = model(x)
+            F.cross_entropy(logits.float(), y, label_smoothing=0.1).backward()
+            cvnets_amd.ops.finish_backward()
+            torch.cuda.synchronize()
+            runs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    assert torch.equal(runs[0][0], runs[1][0])
+    diff = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
+    assert not diff, diff[:8]

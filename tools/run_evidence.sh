@@ -3,7 +3,7 @@
 # (now quoting the fresh profile).      usage: bash tools/run_evidence.sh r03x
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG; O=gpurun_out/$TAG
-(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "^  File" | tail -5) > $O/tests_gpu.log; tail -2 $O/tests_gpu.log
+timeout 1500 python -m pytest tests -q -m gpu > $O/tests_gpu_full.log 2>&1; grep -E "^FAILED|^ERROR| passed| failed" $O/tests_gpu_full.log > $O/tests_gpu.log; rm -f $O/tests_gpu_full.log; cat $O/tests_gpu.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2) > $O/smoke.log; cat $O/smoke.log
 rm -rf $O/prof; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-probe > $O/prof.log 2>&1; tail -1 $O/prof.log | cut -c1-160
 python tools/prof_summary.py $O/prof 60 40 > $O/prof_summary.txt 2>&1; python tools/timeline.py $O/prof > $O/timeline.txt 2>&1; head -3 $O/timeline.txt

@@ -194,6 +194,13 @@ int cvh_bn_dx_weights(int dtype, const float* w, const float* coef, void* wcat, 
  * gradient is streamed once instead of once per product): p_part[cvh_ir_exp_bwd_rows][hid][Cin] float32 partial products, summed with
  * cvh_sum_partials and finished by cvh_bn_dw_combine.  Covers (hid, Cin) = (64, 16), (128, 32), (256, 64) with M >= 65536 — the expansion
  * convs of MobileViT's layer_1 .. layer_3 (cvnets/modules/mobilenetv2.py:180-193); cvh_ir_exp_bwd_rows returns 0 for anything else. */
+/* The projection conv of the same block in the forward pass as a read-dominated stream (csrc/ir_fwd.hip):
+ *   out[M][N] = act(scale * y2 + shift)[M][hid] x wgt[N][hid]^T, stats_part[cvh_ir_red_fwd_rows][2][N] = (sum, sumsq) of the stored values
+ * (NULL: skip) — cvh_pw_gemm_bn with a mode-1 operand transform and e_mode 0, for (hid, N) = (64, 32), (128, 64), (256, 64), (256, 96), bf16,
+ * M >= 65536 (cvnets/modules/mobilenetv2.py:208-219); cvh_ir_red_fwd_rows returns 0 for anything else. */
+int cvh_ir_red_fwd_rows(long long M, int hid, int N);
+int cvh_ir_red_fwd(int dtype, const void* y2, const float* scale, const float* shift, int act, const void* wgt, void* out, float* stats_part,
+                   long long M, int hid, int N, void* stream);
 int cvh_ir_exp_bwd_rows(long long M, int hid, int Cin);
 int cvh_ir_exp_bwd(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
                    float* p_part, long long M, int hid, int Cin, void* stream);

@@ -23,6 +23,7 @@ from . import _lib, ops
 from .ops import ACT_NONE, _dt, _f32, _p, _stream
 
 _IR_EXP_FUSED = __import__("os").environ.get("CVH_IR_EXP_FUSED", "1") != "0"
+_IR_RED_FUSED = __import__("os").environ.get("CVH_IR_RED_FUSED", "1") != "0"
 DW_SHAPE_LOG = None  # set to a list to record the plain dW GEMMs launched from this module (bench.py)
 
 
@@ -162,7 +163,12 @@ class InvertedResidualFn(torch.autograd.Function):
         if training:
             st2 = ops._bn_forward(y2, M2, hid, part, R, g2, b2, rm2, rv2, True, mom[1], eps[1])
         y3 = ops.nhwc_empty(B, Cout, Ho, Wo, dt, dev)
-        part, R = _pw_gemm(y2, _xf(1, None, st2[2], st2[3], None, act2), hid, wp3, y3, M2, Cout, want_stats=training)
+        R3 = _lib.query("cvh_ir_red_fwd_rows", M2, hid, Cout) if (_IR_RED_FUSED and dt == torch.bfloat16) else 0
+        if R3 > 0:  # projection as a read-dominated stream: BN2 + act on the way into LDS, W3 resident (csrc/ir_fwd.hip)
+            part, R = (_f32(R3 * 2 * Cout, dev), R3) if training else (None, 0)
+            _lib.call("cvh_ir_red_fwd", _dt(y2), _p(y2), _p(st2[2]), _p(st2[3]), act2, _p(wp3), _p(y3), _p(part), M2, hid, Cout, _stream())
+        else:
+            part, R = _pw_gemm(y2, _xf(1, None, st2[2], st2[3], None, act2), hid, wp3, y3, M2, Cout, want_stats=training)
         if training:
             st3 = ops._bn_forward(y3, M2, Cout, part, R, g3, b3, rm3, rv3, True, mom[2], eps[2])
         out = ops.nhwc_empty(B, Cout, Ho, Wo, dt, dev)

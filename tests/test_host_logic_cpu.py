@@ -1,0 +1,66 @@
+"""CPU tests of the host-side dispatch logic added with the round-3 kernels (no GPU: only host-only size / eligibility queries of the C ABI
+and the Python predicates in front of them are called)."""
+import torch
+
+
+def test_stem_dispatch_predicate_and_rows():
+    """ops.stem_eligible: the stem kernels take conv_1 of MobileViT / MobileViTv2 on the raw NCHW batch (cvnets/models/classification/mobilevit.py:62-72) and
+    nothing else; cvh_stem_rows = workgroups = partial rows, 0 < rows <= 2048, one per 8 x 64 output tile when there are fewer."""
+    from cvnets_amd import _lib, ops
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        x = torch.zeros(2, 3, 64, 64)
+        w16, w32, w24 = torch.zeros(16, 3, 3, 3), torch.zeros(32, 3, 3, 3), torch.zeros(24, 3, 3, 3)
+        ok = lambda **kw: ops.stem_eligible(kw.get("x", x), kw.get("w", w16), kw.get("bias"), kw.get("s", 2), kw.get("p", 1), kw.get("d", 1),
+                                            kw.get("bn", True), kw.get("res"), kw.get("x2"))
+        assert ok() and ok(w=w32) and ok(x=x.bfloat16())
+        assert not ok(w=w24)                                   # other widths: generic path
+        assert not ok(s=1) and not ok(p=0) and not ok(d=2)     # other geometry
+        assert not ok(bn=False) and not ok(bias=torch.zeros(16)) and not ok(res=x)
+        assert not ok(x=torch.zeros(2, 3, 64, 62))             # W % 4 != 0
+        assert not ok(x=torch.zeros(2, 8, 64, 64))             # not the 3-channel image
+        assert not ok(x=x.clone().requires_grad_(True))        # an image that wants a gradient: the stem has no dX
+        assert not ok(x=x.double())
+        assert not ok(x=x.permute(0, 1, 3, 2))                 # not contiguous NCHW
+        ops.set_compute_dtype(torch.float32)
+        assert not ok()                                        # fp32 compute: generic fp32 kernels
+    finally:
+        ops.set_compute_dtype(None)
+    assert _lib.query("cvh_stem_rows", 1024, 256, 256, 16) == 2048
+    assert _lib.query("cvh_stem_rows", 2, 64, 64, 32) == 2 * 4 * 1
+    assert _lib.load().cvh_stem_rows(2, 64, 62, 16) < 0 and _lib.load().cvh_stem_rows(2, 64, 64, 24) < 0
+
+
+def test_streaming_ir_kernels_cover_exactly_the_big_blocks():
+    """cvh_ir_exp_bwd_rows / cvh_ir_red_fwd_rows: > 0 for the InvertedResidual shapes of MobileViT-S layer_1 .. layer_3 at batch >= 64 k rows,
+    0 (= use the generic GEMMs) for small inputs and for the widths whose weights do not fit LDS beside the tiles."""
+    from cvnets_amd import _lib
+    M = 1024 * 64 * 64
+    assert _lib.query("cvh_ir_exp_bwd_rows", 1024 * 128 * 128, 64, 16) == 1024
+    assert _lib.query("cvh_ir_exp_bwd_rows", 1024 * 128 * 128, 128, 32) == 512
+    assert _lib.query("cvh_ir_exp_bwd_rows", M, 256, 64) == 256
+    assert _lib.query("cvh_ir_exp_bwd_rows", M, 384, 96) == 0 and _lib.query("cvh_ir_exp_bwd_rows", M, 512, 128) == 0
+    assert _lib.query("cvh_ir_exp_bwd_rows", 4096, 256, 64) == 0
+    assert _lib.query("cvh_ir_exp_bwd_rows", 70000, 256, 64) == 256 and _lib.query("cvh_ir_exp_bwd_rows", 65536, 64, 16) == 1024
+    for hid, n, rows in ((64, 32, 1024), (128, 64, 512), (256, 64, 256), (256, 96, 256)):
+        assert _lib.query("cvh_ir_red_fwd_rows", M, hid, n) == rows
+    assert _lib.query("cvh_ir_red_fwd_rows", M, 384, 128) == 0 and _lib.query("cvh_ir_red_fwd_rows", M, 256, 32) == 0
+    assert _lib.query("cvh_ir_red_fwd_rows", 1000, 256, 64) == 0
+
+
+def test_conv_dw_scratch_query_switches_kernels_by_geometry():
+    """cvh_gemm_dw_scratch_elems_conv: a whole number of [N][KH*KW*Cin] partial rows; the 3x3 stride-1 convs of the MobileViT blocks get
+    conv3x3_dw_kernel's row count (512 workgroups shared between the channel slabs), everything else the generic planner's."""
+    from cvnets_amd import _lib
+    B, H = 1024, 32
+    for C1, C2, N, slabs in ((96, 0, 96, 2), (96, 96, 96, 4), (128, 128, 128, 8), (160, 0, 160, 5)):
+        Hh = {96: 32, 128: 16, 160: 8}[N]
+        n = _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, B, Hh, Hh, Hh, Hh, C1, C2, 3, 3, 1, 1, 1, N, 0)
+        row = N * 9 * (C1 + C2)
+        assert n % row == 0 and n // row == 512 // slabs, (N, n // row)
+    M = B * H * H
+    generic = _lib.query("cvh_gemm_dw_scratch_elems", M, 96, 9 * 96)
+    assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 0, B, H, H, H, H, 96, 0, 3, 3, 1, 1, 1, 96, 0) == generic       # fp32: im2col kernel
+    assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, B, H, H, H, H, 96, 0, 3, 3, 1, 1, 1, 96, 1) == generic       # bias folded: im2col kernel
+    assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, B, H, H, H, H, 96, 0, 3, 3, 1, 1, 1, 64, 0) == _lib.query("cvh_gemm_dw_scratch_elems", M, 64, 864)
+    assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, M, 1, 1, 1, 1, 144, 0, 1, 1, 1, 0, 1, 432, 0) == _lib.query("cvh_gemm_dw_scratch_elems", M, 432, 144)

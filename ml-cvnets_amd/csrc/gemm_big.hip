@@ -192,8 +192,11 @@ bool gemm_big_eligible(const ConvGemmParams& p) {
   if (!linear || p.M < 2048 || p.stats_part != nullptr || p.sc_s != 0) return false;
   if (p.N >= 256 && (p.N % BN) == 0 && p.Ktot >= 256 && (p.Ktot % BK) == 0) return true;  // ViT-B / CLIP sized
   // ragged tiles: measured against conv_gemm on the MobileViT linears (M = 65 k ... 1 M rows): ahead for wide outputs
-  // (144 -> 432: 780 -> 620 us, 240 -> 720: 125 -> 58 us), level or behind for N <= 288 where conv_gemm's 96 / 160-column tiles fit exactly
-  return p.N >= 384 && (p.N % 8) == 0 && p.Ktot > 64 && (p.Ktot % 8) == 0;
+  // (144 -> 432: 780 -> 620 us, 240 -> 720: 125 -> 58 us).  Everything with 64 < K <= 320 has gone to gemm_stream_kernel since; what reaches
+  // this test is K > 320 (fc2 forward, fc1 / qkv dX of layer_4 / layer_5 at 65 k - 262 k rows): N >= 192 here is -0.65 ms per step against
+  // conv_gemm's exact 96 / 160-column tiles (same box: 76.6 -> 75.9), N = 144 level
+  const int min_n = cvh_tune_get(CVH_TUNE_BIG_MIN_N) > 0 ? cvh_tune_get(CVH_TUNE_BIG_MIN_N) : 192;
+  return p.N >= min_n && (p.N % 8) == 0 && p.Ktot > 64 && (p.Ktot % 8) == 0;
 }
 
 int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {

@@ -40,3 +40,27 @@ def test_bench_single_rank_line_and_refusal():
     # a launcher that provides a different world size than --gpus must not yield a line
     r = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_committed_step_profile_belongs_to_this_source_tree():
+    """profiles/step_profile.json (what bench.py quotes for roofline.traffic / dominant_kernel) carries a hash of csrc/*, the host package,
+    bench.py and the header; bench.py refuses to quote a profile measured on other sources.  The committed one must match the committed
+    tree, and the tool that writes it must hash the same files as bench.py does."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench_mod)
+    spec2 = importlib.util.spec_from_file_location("msp", os.path.join(REPO, "tools", "make_step_profile.py"))
+    msp = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(msp)
+    assert msp.src_hash() == bench_mod._src_hash()
+    prof = json.load(open(os.path.join(REPO, "profiles", "step_profile.json")))
+    if prof["src_hash"] != bench_mod._src_hash():  # mid-round state: bench.py itself reports the profile as stale and does not quote it
+        import pytest
+        pytest.skip("profiles/step_profile.json was measured on other sources: re-run tools/run_evidence.sh on this tree before the round ends")
+    assert prof["step"]["images"] == 1024 and prof["dominant"] in bench_mod.FAMILIES
+    fam = {f["family"]: f for f in prof["families"]}
+    assert abs(sum(f["ms_per_step"] for f in prof["families"]) - prof["step"]["kernel_time_ms"]) < 0.05 * prof["step"]["kernel_time_ms"]
+    assert fam[prof["dominant"]]["launches_per_step"] > 0

@@ -1,7 +1,7 @@
 """The training step is bit-reproducible: two forward + backward passes of MobileViT-S (bf16, 256 x 256, train-mode BatchNorm, the fused
 InvertedResidual / attention / stem kernels of the benchmark configuration) from the same parameters and batch give IDENTICAL logits
 and gradients.  Every reduction inside the kernels runs in a fixed order (csrc/common.hpp: lds_ordered_accumulate, wave_strided_sum;
-split-M partial rows summed by cvh_reduce_multi's fixed tree) — there is no float atomic on the path.  Dropout is off here only because
+split-M partial rows summed by cvh_reduce_multi's fixed tree) — no float atomic executes in this step.  Dropout is off here only because
 its counter-based masks advance with every forward (cvnets_amd.ops.advance_dropout_seed), as torch's generator would."""
 import pytest
 import torch

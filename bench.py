@@ -40,6 +40,10 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step (BASELINE configs[1]: 1024 on one MI355X; "
                     "the reference recipe's 128/GPU of mobilevit.yaml is --batch 128)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch images per GPU at every N (global batch N x 1024).  strong: --batch is the GLOBAL batch and every "
+                         "GPU gets --batch / N of it — at the default 1024 this is the north-star question: the recipe's global batch 1024 sharded "
+                         "over 8 GPUs = 128 img/GPU")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--mode", default="small")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -54,6 +58,15 @@ def parse(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="control-flow rehearsal on CPU (gloo, no model, no HIP): launch / rendezvous / "
                     "timing / reduction / JSON only — NOT a measurement (tests/test_bench_cpu.py)")
     return ap.parse_args(argv)
+
+
+def per_gpu_batch(args, world: int) -> int:
+    """images per GPU per step: --batch (weak scaling) or --batch / N (strong scaling: --batch is the global batch)"""
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: global batch {args.batch} is not divisible by {world} GPUs")
+        return args.batch // world
+    return args.batch
 
 
 def _cpu_model() -> str:
@@ -257,8 +270,12 @@ def run(args):
     model = cvnets_amd.build_mobilevit(args.mode).to(dev).train()
     # gradients live in flat fp32 buckets (one zero-fill per step, one RCCL message per bucket); with world == 1 the wrapper
     # only provides the flat storage.  Backward kernels add parameter gradients straight into those buffers.
-    ddp = DistributedDataParallel(model, bucket_cap_mb=25.0, broadcast_buffers=False)
-    ddp.hooks_enabled = False  # hipGraph replay does not run autograd hooks: buckets are reduced right after the replay
+    # (buckets: 1 MB first, 8 MB after — MobileViT-S = 4 messages; cvnets_amd/ddp.py)
+    ddp = DistributedDataParallel(model, broadcast_buffers=False)
+    # autograd hooks do not run on a hipGraph REPLAY, but they do run while the step is CAPTURED: the capture below enables them, so the
+    # side-stream fork behind the last gradient kernel of every bucket and the join at the end of backward become graph edges and the
+    # replayed step overlaps the all-reduces with the rest of backward.  Eager steps (warm-up, --no-graph) reduce after backward.
+    ddp.hooks_enabled = False
     cvnets_amd.ops.set_inplace_param_grads(True)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = None
@@ -268,8 +285,9 @@ def run(args):
         else:  # every parameter stepped by one kernel launch, rates and step counter on the device
             opt = cvnets_amd.optim.AdamW(params, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01)
 
-    x = torch.randn(args.batch, 3, args.res, args.res, device=dev)
-    y = torch.randint(0, 1000, (args.batch,), device=dev)
+    pgb = per_gpu_batch(args, world)
+    x = torch.randn(pgb, 3, args.res, args.res, device=dev)
+    y = torch.randint(0, 1000, (pgb,), device=dev)
 
     def zero_grads():
         ddp.zero_grad()
@@ -294,6 +312,7 @@ def run(args):
             opt.step(sync_hyperparameters=False)  # constant rate in this benchmark: the device-side table was filled by the warm-up steps
 
     graph_has_allreduce = False  # True: the bucket all-reduces (side stream fork / join) and the optimizer are nodes of the hipGraph
+    graph_overlapped = 0         # buckets whose all-reduce node starts before the last backward kernel in the captured graph
 
     def step():
         nonlocal static_loss
@@ -343,18 +362,23 @@ def run(args):
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
+                early0 = ddp.early_launches
                 with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
                     ddp.zero_grad()
-                    static_loss = fwd_bwd()
-                    if in_graph:
+                    ddp.hooks_enabled = bool(in_graph) and os.environ.get("CVH_GRAPH_OVERLAP", "1") != "0"
+                    static_loss = fwd_bwd()  # hooks on: every complete bucket forks onto the side stream; `finish` joins at the end of backward
+                    if in_graph and not ddp.hooks_enabled:
                         ddp.allreduce_flat()
+                    ddp.hooks_enabled = False
                     if opt is not None and (not multi or in_graph):
                         opt_step()
                 graph, graph_has_allreduce, graph_err = g, in_graph, None
+                graph_overlapped = ddp.early_launches - early0
                 break
             except Exception as e:  # pragma: no cover - reported in the JSON line
                 graph_err = f"{type(e).__name__}: {e}"[:300]
                 graph = None
+                ddp.hooks_enabled = False
                 torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -385,6 +409,8 @@ def run(args):
         headline = args.mode == "small" and args.res == 256 and args.dtype == "bf16"
         out["config"].update({"hipgraph": graph is not None, "dropout": 0.1, "loss": round(loss_val, 4),
                               "allreduce": ("in-graph (RCCL, side stream)" if graph_has_allreduce else "after replay (RCCL, side stream)") if multi else None,
+                              "allreduce_buckets": ddp.overlap_report()["bucket_mb"] if multi else None,
+                              "allreduce_buckets_started_inside_backward": graph_overlapped if (multi and graph_has_allreduce) else None,
                               "step": "zero_grad+fwd+CE(ls=0.1)+bwd" + ("+allreduce" if multi else "") +
                                       ("" if opt is None else ("+AdamW(torch fused)" if args.torch_optimizer else "+AdamW(cvh_adamw_multi)"))})
         if graph_err:
@@ -451,7 +477,8 @@ def run(args):
 
 def report(args, world, wall, gpu_ms_per_step=None):
     """the JSON line (rank 0) from the max-over-ranks wall time of the timed region"""
-    imgs = args.batch * world * args.steps
+    pgb = per_gpu_batch(args, world)
+    imgs = pgb * world * args.steps
     value = imgs / wall
     per_gpu = value / world
     t_img = 1.0 / per_gpu
@@ -480,11 +507,12 @@ def report(args, world, wall, gpu_ms_per_step=None):
         "warmup": args.warmup,
         "ms_per_step": round(wall * 1e3 / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic (randn images, random-init weights)" if not args.dry_run else "dry-run (control-flow rehearsal on CPU: NOT a measurement)",
-        "config": {"workload": f"MobileViT-{args.mode} {args.res}x{args.res}, {args.batch} img/GPU, global batch {args.batch * world}",
+        "config": {"workload": f"MobileViT-{args.mode} {args.res}x{args.res}, {pgb} img/GPU, global batch {pgb * world}"
+                               + (" (strong scaling: the global batch is fixed, sharded over the GPUs)" if args.scaling == "strong" else ""),
                    "parallelism": f"dp{world}"},
         "images_per_sec_per_gpu": round(per_gpu, 2),
         "roofline": roofline,

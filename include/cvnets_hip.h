@@ -182,6 +182,25 @@ int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand_xf* dy_xf,
                       const void* wp, void* g_in, float* stats_part, float* dw_part, int B, int H, int W, int Ho, int Wo, int C, int stride,
                       void* stream);
 
+/* The wide half of InvertedResidual.forward (cvnets/modules/mobilenetv2.py:180-207,231-235: exp 1x1 -> BatchNorm -> act -> depthwise 3x3 ->
+ * BatchNorm) with the 4x-wide expansion output y1 = x W1^T never in HBM (bf16; Cin in {16, 32, 64, 96, 128}, stride 1 only up to 64;
+ * hid % 8 == 0), everything GEMM- or stencil-shaped on the matrix pipe (csrc/dwx.hip):
+ *   cvh_gram_bn_stats  one partial-statistics row part[2][hid] = (sum y1, sum y1^2) for cvh_bn_finalize from the Gram matrix G = x^T x
+ *                      ([K] rows of pitch Gp: cvh_gemm_dw on (x, x)) and s = 1^T x (cvh_colsum) of the NARROW input — y1 is linear in x;
+ *   cvh_dwx_fwd        y2 = dwconv(act(scale1 * (x W1^T) + shift1)), statistics of y2 -> stats_part[cvh_dwx_rows()][2][hid] (NULL: skip);
+ *   cvh_dwx_bwd        g_in = dwconv^T(dy) * act'(bn1(y1)) with y1 recomputed from x at the tile's own pixels, dy = ca * g_out + cb * y_out
+ *                      + cc (y_out == NULL: dy = g_out); dw_part[rows][hid * 9] = per-workgroup depthwise weight gradients,
+ *                      stats_part[rows][2][hid] = (sum g_in, sum g_in * xhat1).  in_stats = [4][hid] (mean, invstd, scale, shift).
+ * w1 = [hid][Cin], wd = [9][hid] packed weights (cvh_weight_pack).  Replaces Conv2d(1x1) + BatchNorm2d + SiLU + Conv2d(groups = C) and
+ * their autograd backward; returns -2 for geometries it does not cover (callers fall back to cvh_pw_gemm_bn + cvh_dwconv_bn_*). */
+int cvh_dwx_rows(int B, int Ho, int Wo, int hid, int stride);
+int cvh_gram_bn_stats(const float* G, const float* s, const void* w1, float* part, int hid, int K, int Gp, void* stream);
+int cvh_dwx_fwd(int dtype, const void* x, const void* w1, const float* scale1, const float* shift1, int act1, const void* wd, void* y2,
+                float* stats_part, int B, int H, int W, int Ho, int Wo, int Cin, int hid, int stride, void* stream);
+int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float* in_stats, int act1, const void* g_out, const void* y_out,
+                const float* ca, const float* cb, const float* cc, const void* wd, void* g_in, float* stats_part, float* dw_part,
+                int B, int H, int W, int Ho, int Wo, int Cin, int hid, int stride, void* stream);
+
 /* Linear side of a BatchNorm link (y = x W^T in front of the BatchNorm, e.g. the 1x1 expansion conv): with coef[3][N] = (ca, cb, cc) of
  * cvh_bn_bwd_finalize and g = dz * act'(bn(y)),
  *   dX = g (diag(ca) W) + x (W^T diag(cb) W) + 1 (cc^T W): cvh_bn_dx_weights writes wcat[pad8(K)][N + pad8(K)] (`dtype`) and

@@ -1,0 +1,762 @@
+// dwx kernels: the wide half of an InvertedResidual block (cvnets/modules/mobilenetv2.py:180-207,231-235: 1x1 expansion conv -> BatchNorm
+// -> SiLU -> depthwise 3x3 conv (pad 1, stride 1 / 2) -> BatchNorm) with the 4x-wide expansion output y1 = x W1^T NEVER in HBM, bf16.
+//
+//   forward   y2 = dwconv(act(bn1(x W1^T)))        reads the NARROW block input x (tile + halo), writes y2, emits the statistics of y2
+//   backward  g1 = dwconv^T(dy2) * act'(bn1(y1))   y1 recomputed from x at the tile's own pixels; dW of the depthwise conv, statistics of g1
+//
+// Everything GEMM-shaped or stencil-shaped runs on the matrix pipe (v_mfma_f32_16x16x32_bf16), which the HBM-bound step leaves idle:
+//   * y1^T[ch][px] = W1[ch][:] . x[px][:]                                    A = W1 rows (resident in registers), B = x tile rows (LDS)
+//   * the depthwise stencil as a product with DIAGONAL weight blocks:         out^T[c][px] = sum_(tap, c') diag(w_tap)[c][c'] a[px + tap][c']
+//     two taps share one K = 32 step (k = 16 * slot + c'), i.e. 5 MFMAs per 16 pixels x 16 channels; the B operand of a tap is simply
+//     the 16-byte channel group of the shifted pixel — stride 2 and the transposed (backward) stencil are address arithmetic only
+//   * the depthwise weight gradient dW[tap][c] = sum_px dy[px - tap][c] z[px][c] as the DIAGONAL of dy_shifted^T z per 16-channel block
+//     (transpose-read operands, K = pixels)
+// so the VALU is left with BatchNorm + SiLU (+ SiLU') per element, packing and the statistics — about half of what the LDS-stencil
+// kernels of dwfused.hip issue — and the accumulators of the weight gradient no longer live 72-per-lane in the register file.
+//
+// A workgroup = 4 waves = one 64-channel chunk of one spatial tile; wave w owns channels 16w .. 16w+15 of the chunk in EVERY phase, so the
+// activation tile it writes (its own 32-byte column group of each pixel row) is wave-private: between the phases there is no workgroup
+// barrier, only the two around the refresh of the shared x tile.  Accumulator layout of the MFMA (lane = 1 pixel x 4 consecutive
+// channels) is the layout of every epilogue; results leave as 8-byte stores (32 contiguous bytes per pixel and wave).
+// BatchNorm of the expansion needs its batch statistics BEFORE this kernel runs: y1 is linear in x, so sum y1 = W1 (sum x) and
+// sum y1^2 = diag(W1 (x^T x) W1^T) come from the K x K Gram matrix of the narrow input (gram_bn_stats_kernel) — the same Gram matrix the
+// backward pass needs for the weight gradient (cvh_bn_dw_combine), computed once.
+#include "common.hpp"
+#include "cvnets_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+constexpr int DX_CC = 64;  // channels per workgroup: 4 waves x 16
+constexpr int DX_AP = 80;  // LDS pixel pitch (elements) of the activation / gradient tiles: 160 B — 16 consecutive pixels x 16 B cover all 64 banks
+
+template <int S> struct DxTile;
+template <> struct DxTile<1> {  // 8 x 16 outputs <- 10 x 18 inputs
+  static constexpr int OH = 8, OW = 16, IH = 10, IW = 18;
+};
+template <> struct DxTile<2> {  // 4 x 8 outputs <- 9 x 17 inputs
+  static constexpr int OH = 4, OW = 8, IH = 9, IW = 17;
+};
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+// A operand of the diagonal-weight product for tap pair tp: A[c = l15][k = 8 * l4 + j] = (16 * slot + c' == k ? w[2 tp + slot][c] : 0)
+__device__ __forceinline__ bf16x8_t diag_frag(const bf16_t* wd /*[9][C]*/, int C, int ch, int tp, int l15, int l4, bool flip) {
+  int tap = 2 * tp + (l4 >> 1);
+  uint16_t wv = 0;
+  if (tap < 9 && ch < C && (l15 >> 3) == (l4 & 1)) wv = wd[(size_t)(flip ? 8 - tap : tap) * C + ch].v;
+  v8s f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (j == (l15 & 7)) ? (short)wv : (short)0;
+  return __builtin_bit_cast(bf16x8_t, f);
+}
+
+struct DwxFwdParams {
+  const bf16_t* x;      // [B*H*W][Cin]
+  const bf16_t* w1;     // [hid][Cin]
+  const float* scale1;  // [hid] BatchNorm of the expansion: scale, shift
+  const float* shift1;
+  const bf16_t* wd;     // [9][hid]
+  bf16_t* y2;           // [B*Ho*Wo][hid]
+  float* stats_part;    // [rows][2][hid] or nullptr
+  int act1;
+  int B, H, W, Ho, Wo, hid;
+  int tiles_h, tiles_w, ntiles, chunks;
+};
+
+template <int S, int CIN>
+__global__ __launch_bounds__(256, 2) void dwx_fwd_kernel(DwxFwdParams p) {
+  using TL = DxTile<S>;
+  constexpr int KS = (CIN + 31) / 32, XP = 32 * KS + 8, XC = CIN / 8;
+  constexpr int NPIX = TL::IH * TL::IW, NPB = (NPIX + 15) / 16, NOB = TL::OH * TL::OW / 16;
+  constexpr int NXL = (NPIX * XC + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [NPB * 16][XP]   block input, tile + halo (zero outside the image / past CIN)
+  bf16_t* at = xs + NPB * 16 * XP;                   // [NPB * 16][DX_AP] act(bn1(y1)) of this workgroup's 64 channels
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int chunk = lb % p.chunks, row_id = lb / p.chunks;
+  const int cw = chunk * DX_CC + 16 * wave;  // first channel of this wave
+  const int hid = p.hid;
+
+  for (int i = tid; i < NPB * 16 * XP / 8; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+
+  bf16x8_t w1f[KS], wdf[5];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int ch = cw + l15, k = 32 * ks + 8 * l4;
+    if (ch < hid && k < CIN) v = *reinterpret_cast<const uint4*>(p.w1 + (size_t)ch * CIN + k);
+    w1f[ks] = __builtin_bit_cast(bf16x8_t, v);
+  }
+#pragma unroll
+  for (int tp = 0; tp < 5; ++tp) wdf[tp] = diag_frag(p.wd, hid, cw + l15, tp, l15, l4, false);
+  float sc[4], sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ch = cw + 4 * l4 + e;
+    sc[e] = ch < hid ? p.scale1[ch] : 0.f;
+    sh[e] = ch < hid ? p.shift1[ch] : 0.f;
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // LDS offsets (elements) of the lane's B-operand reads in the stencil phase: tap (2 tp + slot), clamped to a real tap for the idle slot
+  int toff[5];
+#pragma unroll
+  for (int tp = 0; tp < 5; ++tp) {
+    int tap = 2 * tp + (l4 >> 1);
+    tap = tap > 8 ? 8 : tap;
+    toff[tp] = ((tap / 3) * TL::IW + (tap % 3)) * DX_AP + 16 * wave + 8 * (l4 & 1);
+  }
+
+  const int t_step = gridDim.x / p.chunks;
+  uint4 xr[NXL];
+  uint32_t xok = 0;
+  auto load_x = [&](int tix) __attribute__((always_inline)) {
+    const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
+    const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
+    const int hi0 = th * TL::OH * S - 1, wi0 = tw * TL::OW * S - 1;
+    xok = 0;
+#pragma unroll
+    for (int it = 0; it < NXL; ++it) {
+      const int i = tid + it * 256;
+      const int px = i / XC, ck = i - px * XC;
+      const int pr = px / TL::IW, pc = px - pr * TL::IW;
+      const int hi = hi0 + pr, wi = wi0 + pc;
+      const bool ok = i < NPIX * XC && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      xok |= (ok ? 1u : 0u) << it;
+      xr[it] = *reinterpret_cast<const uint4*>(p.x + (ok ? (((size_t)b * p.H + hi) * p.W + wi) * CIN + ck * 8 : (size_t)0));
+    }
+  };
+
+  int tix = row_id;
+  if (tix < p.ntiles) load_x(tix);
+  for (; tix < p.ntiles; tix += t_step) {
+    const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
+    const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
+    const int ho0 = th * TL::OH, wo0 = tw * TL::OW;
+    const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
+
+    __syncthreads();  // every wave is done with the previous x tile (first iteration: the zero fill is complete)
+#pragma unroll
+    for (int it = 0; it < NXL; ++it) {
+      const int i = tid + it * 256;
+      const int px = i / XC, ck = i - px * XC;
+      if (i < NPIX * XC) {
+        uint4 v = xr[it];
+        if (!((xok >> it) & 1u)) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(xs + px * XP + ck * 8) = v;
+      }
+    }
+    __syncthreads();
+    if (tix + t_step < p.ntiles) load_x(tix + t_step);  // next tile's input, in flight under this tile's arithmetic
+
+    // pixels of the halo tile that lie inside the image (the conv's zero padding applies to the ACTIVATED tensor)
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      const int px = 16 * pb + l15;
+      const int pr = px / TL::IW, pc = px - pr * TL::IW;
+      const int hi = hi0 + pr, wi = wi0 + pc;
+      vmask |= ((px < NPIX && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) ? 1u : 0u) << pb;
+    }
+
+    // ---- expansion + BatchNorm + activation -> activation tile (this wave's 16 channels of every pixel) ----
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      const bf16_t* xrow = xs + (16 * pb + l15) * XP + 8 * l4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma16(w1f[ks], *reinterpret_cast<const bf16x8_t*>(xrow + 32 * ks), acc);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yh = sc[e] * rbf(acc[e]) + sh[e];  // y1 as it would read back from a bf16 tensor
+        v[e] = yh * sigmoidf_(yh);                      // SiLU (the only activation these kernels are compiled for: a run-time dispatch per
+                                                        // element cuts the unrolled epilogues into basic blocks the scheduler cannot interleave)
+      }
+      if (!((vmask >> pb) & 1u)) v[0] = v[1] = v[2] = v[3] = 0.f;
+      *reinterpret_cast<uint2*>(at + (16 * pb + l15) * DX_AP + 16 * wave + 4 * l4) = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+    }
+    wave_lds_sync();
+
+    // ---- depthwise stencil on the matrix pipe ----
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+      const int orow = S == 1 ? ob : 2 * ob + (l15 >> 3), ocol = S == 1 ? l15 : (l15 & 7);
+      const bf16_t* base = at + ((orow * S) * TL::IW + ocol * S) * DX_AP;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp) acc = mfma16(wdf[tp], *reinterpret_cast<const bf16x8_t*>(base + toff[tp]), acc);
+      const int ho = ho0 + orow, wo = wo0 + ocol, ch = cw + 4 * l4;
+      if (ho < p.Ho && wo < p.Wo && ch < hid) {
+        const uint2 pk = make_uint2(f2bf_pk(acc[0], acc[1]), f2bf_pk(acc[2], acc[3]));
+        *reinterpret_cast<uint2*>(p.y2 + (((size_t)b * p.Ho + ho) * p.Wo + wo) * hid + ch) = pk;
+        const float q[4] = {bf2f((uint16_t)(pk.x & 0xffff)), bf2f((uint16_t)(pk.x >> 16)), bf2f((uint16_t)(pk.y & 0xffff)),
+                            bf2f((uint16_t)(pk.y >> 16))};  // statistics of the values as stored
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += q[e];
+          s2[e] += q[e] * q[e];
+        }
+      }
+    }
+  }
+
+  if (p.stats_part != nullptr) {
+    // a lane's 4 channels are shared with the 15 other pixel lanes of its group: fixed butterfly, then one lane per group writes
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        s1[e] += __shfl_xor(s1[e], m, 64);
+        s2[e] += __shfl_xor(s2[e], m, 64);
+      }
+    if (l15 == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ch = cw + 4 * l4 + e;
+        if (ch < hid) {
+          p.stats_part[((size_t)row_id * 2 + 0) * hid + ch] = s1[e];
+          p.stats_part[((size_t)row_id * 2 + 1) * hid + ch] = s2[e];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A operand of a diagonal-weight product whose two K slots carry the weights with indices wa / wb (kh * 3 + kw; -1: empty slot)
+__device__ __forceinline__ bf16x8_t diag_frag2(const bf16_t* wd /*[9][C]*/, int C, int ch, int wa, int wb, int l15, int l4) {
+  const int wi = (l4 >> 1) ? wb : wa;
+  uint16_t wv = 0;
+  if (wi >= 0 && ch < C && (l15 >> 3) == (l4 & 1)) wv = wd[(size_t)wi * C + ch].v;
+  v8s f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (j == (l15 & 7)) ? (short)wv : (short)0;
+  return __builtin_bit_cast(bf16x8_t, f);
+}
+__device__ __forceinline__ bf16x8_t tr_frag8(const bf16_t* lo, const bf16_t* hi) {
+  const tr_v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(lo));
+  const tr_v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(hi));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// Tile of the backward kernel = the OWN input pixels of a forward tile: 8 x 16 (both strides), as eight 16-pixel blocks.
+//   stride 1: block pb = tile row pb; the dy tile is the 10 x 18 halo image of the output tile (origin (-1, -1)).
+//   stride 2: 8 x 16 inputs <-> 4 x 8 outputs; dy tile 5 x 9 (origin (0, 0): an odd input row also reads the output row below).  A block
+//             holds pixels of ONE parity class (ph, pw) — the taps that reach an input pixel depend on its parity only:
+//             hi = 2 ho + kh - 1  =>  even row: kh = 1;  odd row: kh = 0 (ho = (hi + 1) / 2) and kh = 2 (ho = (hi - 1) / 2) — so the
+//             16 pixels of a block share one weight operand: 1 + 1 + 1 + 2 MFMAs for the four classes (9 taps), 5 per 64 pixels.
+template <int S> struct DxBwd;
+template <> struct DxBwd<1> {
+  static constexpr int DH = 10, DW = 18;
+};
+template <> struct DxBwd<2> {
+  static constexpr int DH = 5, DW = 9;
+};
+// stride 2: weight indices of the two K slots of MFMA m of parity class cls = 2 ph + pw (-1: none)
+__host__ __device__ constexpr int dx2_tap(int cls, int m, int slot) {
+  return cls == 0 ? (slot == 0 ? 4 : -1)
+       : cls == 1 ? (slot == 0 ? 3 : 5)
+       : cls == 2 ? (slot == 0 ? 1 : 7)
+       : (m == 0 ? (slot == 0 ? 0 : 2) : (slot == 0 ? 6 : 8));
+}
+
+struct DwxBwdParams {
+  const bf16_t* x;         // [B*H*W][Cin] block input
+  const bf16_t* w1;        // [hid][Cin]
+  const float* in_stats;   // [4][hid] mean, invstd, scale, shift of the expansion BatchNorm
+  const bf16_t* g_out;     // [B*Ho*Wo][hid] g2
+  const bf16_t* y_out;     // [B*Ho*Wo][hid] y2 (nullptr: dy = g_out as it is)
+  const float* ca;         // [hid] dy = ca * g_out + cb * y_out + cc
+  const float* cb;
+  const float* cc;
+  const bf16_t* wd;        // [9][hid]
+  bf16_t* g_in;            // [B*H*W][hid] g1 = dwconv^T(dy) * act'(bn1(y1))
+  float* stats_part;       // [rows][2][hid] sum g1, sum g1 * xhat1
+  float* dw_part;          // [rows][hid * 9]
+  int act1;
+  int B, H, W, Ho, Wo, hid;
+  int tiles_h, tiles_w, ntiles, chunks;
+};
+
+template <int S, int CIN>
+__global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
+  using TL = DxTile<S>;
+  using TB = DxBwd<S>;
+  constexpr int KS = (CIN + 31) / 32, XP = 32 * KS + 8, XC = CIN / 8;
+  constexpr int ND = TB::DH * TB::DW, NLD = (ND * 8 + 255) / 256, NXL = (128 * XC + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* dt = reinterpret_cast<bf16_t*>(smem_raw);   // [ND][DX_AP]  dy of this workgroup's 64 channels (zero outside the image)
+  bf16_t* zt = dt + ND * DX_AP;                        // [128][DX_AP] z = act(bn1(y1)) at the own pixels
+  bf16_t* xo = zt + 128 * DX_AP;                       // [128][XP]    block input at the own pixels
+  float* cst = reinterpret_cast<float*>(xo + 128 * XP);  // [7][64] ca, cb, cc; mean, invstd, scale, shift
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int chunk = lb % p.chunks, row_id = lb / p.chunks;
+  const int c0 = chunk * DX_CC, cw = c0 + 16 * wave;
+  const int hid = p.hid;
+  const bool two_src = p.y_out != nullptr;
+
+  for (int i = tid; i < 128 * XP / 8; i += 256) reinterpret_cast<uint4*>(xo)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 3 * DX_CC; i += 256) {
+    const int v = i / DX_CC, c = c0 + (i - v * DX_CC);
+    const float* src = v == 0 ? p.ca : (v == 1 ? p.cb : p.cc);
+    cst[i] = (two_src && c < hid) ? src[c] : 0.f;
+  }
+
+  bf16x8_t w1f[KS], wdf[5];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int ch = cw + l15, k = 32 * ks + 8 * l4;
+    if (ch < hid && k < CIN) v = *reinterpret_cast<const uint4*>(p.w1 + (size_t)ch * CIN + k);
+    w1f[ks] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  if (S == 1) {
+    // slot tap t' = halo offset (dh, dw) = (t' / 3, t' % 3) of the dy tile; its weight is w[2 - dh][2 - dw] = index 8 - t'
+#pragma unroll
+    for (int tp = 0; tp < 5; ++tp) wdf[tp] = diag_frag2(p.wd, hid, cw + l15, 8 - 2 * tp, 2 * tp + 1 < 9 ? 8 - (2 * tp + 1) : -1, l15, l4);
+  } else {
+    wdf[0] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(0, 0, 0), dx2_tap(0, 0, 1), l15, l4);
+    wdf[1] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(1, 0, 0), dx2_tap(1, 0, 1), l15, l4);
+    wdf[2] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(2, 0, 0), dx2_tap(2, 0, 1), l15, l4);
+    wdf[3] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(3, 0, 0), dx2_tap(3, 0, 1), l15, l4);
+    wdf[4] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(3, 1, 0), dx2_tap(3, 1, 1), l15, l4);
+  }
+  // mean, invstd, scale, shift of this workgroup's channels: read from LDS where they are used (16 registers otherwise)
+  for (int i = tid; i < 4 * DX_CC; i += 256) {
+    const int v = i / DX_CC, c = c0 + (i - v * DX_CC);
+    cst[3 * DX_CC + i] = c < hid ? p.in_stats[(size_t)v * hid + c] : 0.f;
+  }
+  const float* bn1 = cst + 3 * DX_CC + 16 * wave + 4 * l4;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t dwa[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dwa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int slot = l4 >> 1;
+  const int chof = 16 * wave + 8 * (l4 & 1);  // B-operand channel group of the stencil products
+  const int q4 = 16 * wave + 4 * (l15 & 3), rsub = l15 >> 2;  // transpose reads: column group and pixel sub-row this lane addresses
+
+  const int t_step = gridDim.x / p.chunks;
+  uint4 gr[NLD], yr[NLD], xr[NXL];
+  uint32_t dok = 0, xok = 0;
+  auto load_tile = [&](int tix) __attribute__((always_inline)) {
+    const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
+    const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
+    const int ho0 = th * TL::OH, wo0 = tw * TL::OW;
+    const int dh0 = S == 1 ? ho0 - 1 : ho0, dw0 = S == 1 ? wo0 - 1 : wo0;
+    const int hi0 = ho0 * S, wi0 = wo0 * S;
+    dok = 0;
+    xok = 0;
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+      const int i = tid + it * 256;
+      const int px = i >> 3, cg = i & 7;
+      const int pr = px / TB::DW, pc = px - pr * TB::DW;
+      const int ho = dh0 + pr, wo = dw0 + pc;
+      const bool ok = px < ND && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo && c0 + cg * 8 < hid;
+      dok |= (ok ? 1u : 0u) << it;
+      const size_t o = ok ? (((size_t)b * p.Ho + ho) * p.Wo + wo) * hid + c0 + cg * 8 : (size_t)0;
+      gr[it] = *reinterpret_cast<const uint4*>(p.g_out + o);
+      yr[it] = *reinterpret_cast<const uint4*>((two_src ? p.y_out : p.g_out) + o);
+    }
+#pragma unroll
+    for (int it = 0; it < NXL; ++it) {
+      const int i = tid + it * 256;
+      const int px = i / XC, ck = i - px * XC;
+      const int hi = hi0 + (px >> 4), wi = wi0 + (px & 15);
+      const bool ok = i < 128 * XC && hi < p.H && wi < p.W;
+      xok |= (ok ? 1u : 0u) << it;
+      xr[it] = *reinterpret_cast<const uint4*>(p.x + (ok ? (((size_t)b * p.H + hi) * p.W + wi) * CIN + ck * 8 : (size_t)0));
+    }
+  };
+
+  int tix = row_id;
+  if (tix < p.ntiles) load_tile(tix);
+  for (; tix < p.ntiles; tix += t_step) {
+    const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
+    const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
+    const int hi0 = th * TL::OH * S, wi0 = tw * TL::OW * S;
+
+    __syncthreads();  // every wave is done with the previous tile (first iteration: the zero fill and the coefficients are in place)
+    {
+      float ka[8], kb[8], kc[8];
+      const int cg = tid & 7;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ka[j] = 1.f; kb[j] = 0.f; kc[j] = 0.f; }
+      if (two_src) {
+        *reinterpret_cast<float4*>(ka) = *reinterpret_cast<const float4*>(cst + cg * 8);
+        *reinterpret_cast<float4*>(ka + 4) = *reinterpret_cast<const float4*>(cst + cg * 8 + 4);
+        *reinterpret_cast<float4*>(kb) = *reinterpret_cast<const float4*>(cst + DX_CC + cg * 8);
+        *reinterpret_cast<float4*>(kb + 4) = *reinterpret_cast<const float4*>(cst + DX_CC + cg * 8 + 4);
+        *reinterpret_cast<float4*>(kc) = *reinterpret_cast<const float4*>(cst + 2 * DX_CC + cg * 8);
+        *reinterpret_cast<float4*>(kc + 4) = *reinterpret_cast<const float4*>(cst + 2 * DX_CC + cg * 8 + 4);
+      }
+#pragma unroll
+      for (int it = 0; it < NLD; ++it) {
+        const int i = tid + it * 256;
+        const int px = i >> 3;
+        if (px < ND) {
+          V8<bf16_t> o;
+          o.d = make_uint4(0, 0, 0, 0);
+          if ((dok >> it) & 1u) {
+            V8<bf16_t> gv, yv;
+            gv.d = gr[it];
+            yv.d = yr[it];
+            if (two_src) {
+              float g[8], y[8];
+              v8_unpack(gv, g);
+              v8_unpack(yv, y);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) g[j] = ka[j] * g[j] + kb[j] * y[j] + kc[j];
+              v8_pack(g, o);
+            } else {
+              o = gv;
+            }
+          }
+          *reinterpret_cast<uint4*>(dt + px * DX_AP + cg * 8) = o.d;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NXL; ++it) {
+        const int i = tid + it * 256;
+        const int px = i / XC, ck = i - px * XC;
+        if (i < 128 * XC) {
+          uint4 v = xr[it];
+          if (!((xok >> it) & 1u)) v = make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(xo + px * XP + ck * 8) = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (tix + t_step < p.ntiles) load_tile(tix + t_step);  // next tile's operands, in flight under this tile's arithmetic
+
+    // ---- per 16-pixel block: y1 -> z, act', xhat;  dz = stencil^T(dy);  g1 = dz * act' ----
+    // (not unrolled: eight blocks' worth of hoisted operand reads would push the persistent accumulators into scratch)
+#pragma unroll 1
+    for (int pb = 0; pb < 8; ++pb) {
+      // tile coordinates of this lane's pixel
+      int r, c;
+      if (S == 1) {
+        r = pb;
+        c = l15;
+      } else {
+        const int cls = pb >> 1, half = pb & 1;
+        r = (cls >> 1) + 2 * (2 * half + (l15 >> 3));
+        c = (cls & 1) + 2 * (l15 & 7);
+      }
+      const int opx = r * 16 + c;
+      const int hi = hi0 + r, wi = wi0 + c;
+      const bool pok = hi < p.H && wi < p.W;
+
+      f32x4_t a1 = {0.f, 0.f, 0.f, 0.f};
+      const bf16_t* xrow = xo + opx * XP + 8 * l4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a1 = mfma16(w1f[ks], *reinterpret_cast<const bf16x8_t*>(xrow + 32 * ks), a1);
+
+      f32x4_t a2 = {0.f, 0.f, 0.f, 0.f};
+      if (S == 1) {
+#pragma unroll
+        for (int tp = 0; tp < 5; ++tp) {
+          int t = 2 * tp + slot;
+          t = t > 8 ? 8 : t;
+          const int dpx = (r + t / 3) * TB::DW + c + t % 3;
+          a2 = mfma16(wdf[tp], *reinterpret_cast<const bf16x8_t*>(dt + dpx * DX_AP + chof), a2);
+        }
+      } else {
+        // the weight operand and the tap geometry depend on the parity class: wave-uniform dispatch on it
+        const int cls = pb >> 1;
+        const int rr = r >> 1, cc = c >> 1;
+        auto tap_mma = [&](const bf16x8_t& wf, int ta, int tb) __attribute__((always_inline)) {
+          int wi_ = slot ? tb : ta;
+          wi_ = wi_ < 0 ? ta : wi_;  // empty slot: zero weights, any valid address
+          const int kh = wi_ / 3, kw = wi_ - 3 * kh;
+          const int dpx = (rr + (kh == 0 ? 1 : 0)) * TB::DW + cc + (kw == 0 ? 1 : 0);
+          a2 = mfma16(wf, *reinterpret_cast<const bf16x8_t*>(dt + dpx * DX_AP + chof), a2);
+        };
+        if (cls == 0) tap_mma(wdf[0], dx2_tap(0, 0, 0), dx2_tap(0, 0, 1));
+        else if (cls == 1) tap_mma(wdf[1], dx2_tap(1, 0, 0), dx2_tap(1, 0, 1));
+        else if (cls == 2) tap_mma(wdf[2], dx2_tap(2, 0, 0), dx2_tap(2, 0, 1));
+        else {
+          tap_mma(wdf[3], dx2_tap(3, 0, 0), dx2_tap(3, 0, 1));
+          tap_mma(wdf[4], dx2_tap(3, 1, 0), dx2_tap(3, 1, 1));
+        }
+      }
+
+      float z[4], gp[4], xh[4], mu[4], is[4], sc[4], sh[4];
+      *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(bn1);
+      *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(bn1 + DX_CC);
+      *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(bn1 + 2 * DX_CC);
+      *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(bn1 + 3 * DX_CC);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y1 = rbf(a1[e]);  // y1 as the forward kernel saw it
+        const float yh = sc[e] * y1 + sh[e];
+        const float sg = sigmoidf_(yh);  // SiLU and its derivative from one sigmoid
+        z[e] = yh * sg;
+        gp[e] = sg * (1.0f + yh * (1.0f - sg));
+        xh[e] = (y1 - mu[e]) * is[e];
+      }
+      if (!pok) z[0] = z[1] = z[2] = z[3] = 0.f;
+      *reinterpret_cast<uint2*>(zt + opx * DX_AP + 16 * wave + 4 * l4) = make_uint2(f2bf_pk(z[0], z[1]), f2bf_pk(z[2], z[3]));
+      const int ch = cw + 4 * l4;
+      if (pok && ch < hid) {
+        const uint2 pk = make_uint2(f2bf_pk(a2[0] * gp[0], a2[1] * gp[1]), f2bf_pk(a2[2] * gp[2], a2[3] * gp[3]));
+        *reinterpret_cast<uint2*>(p.g_in + (((size_t)b * p.H + hi) * p.W + wi) * hid + ch) = pk;
+        const float q[4] = {bf2f((uint16_t)(pk.x & 0xffff)), bf2f((uint16_t)(pk.x >> 16)), bf2f((uint16_t)(pk.y & 0xffff)),
+                            bf2f((uint16_t)(pk.y >> 16))};  // statistics of the values as stored
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += q[e];
+          s2[e] += q[e] * xh[e];
+        }
+      }
+    }
+    wave_lds_sync();
+
+    // ---- depthwise weight gradient: diagonal of dy_shifted^T z, contraction over the tile's own pixels ----
+    if (S == 1) {
+      // K step ks = tile rows 2 ks, 2 ks + 1; K slot (l4, j) <-> pixel (row 2 ks + (j >> 2), column 4 l4 + (j & 3))
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {
+        const int col = 4 * l4 + rsub;
+        const bf16_t* zlo = zt + ((2 * ks) * 16 + col) * DX_AP + q4;
+        const bf16x8_t zb = tr_frag8(zlo, zlo + 16 * DX_AP);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const bf16_t* dlo = dt + ((2 * ks + t / 3) * TB::DW + col + t % 3) * DX_AP + q4;
+          dwa[8 - t] = mfma16(tr_frag8(dlo, dlo + TB::DW * DX_AP), zb, dwa[8 - t]);
+          if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // at most three taps' operand reads in flight (registers)
+        }
+      }
+    } else {
+      // one K step per parity class: K slot (l4, j) <-> class pixel (rr = l4, cc = j)
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        const bf16_t* zlo = zt + ((ph + 2 * l4) * 16 + pw + 2 * rsub) * DX_AP + q4;
+        const bf16x8_t zb = tr_frag8(zlo, zlo + 8 * DX_AP);
+#pragma unroll
+        for (int m = 0; m < (cls == 3 ? 2 : 1); ++m)
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            const int wi_ = dx2_tap(cls, m, sl);
+            if (wi_ >= 0) {
+              const int kh = wi_ / 3, kw = wi_ - 3 * kh;
+              const bf16_t* dlo = dt + ((l4 + (kh == 0 ? 1 : 0)) * TB::DW + rsub + (kw == 0 ? 1 : 0)) * DX_AP + q4;
+              dwa[wi_] = mfma16(tr_frag8(dlo, dlo + 4 * DX_AP), zb, dwa[wi_]);
+            }
+          }
+      }
+    }
+  }
+
+  // ---- workgroup results: statistics and the diagonal of the dW accumulators ----
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      s1[e] += __shfl_xor(s1[e], m, 64);
+      s2[e] += __shfl_xor(s2[e], m, 64);
+    }
+  if (l15 == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ch = cw + 4 * l4 + e;
+      if (ch < hid) {
+        p.stats_part[((size_t)row_id * 2 + 0) * hid + ch] = s1[e];
+        p.stats_part[((size_t)row_id * 2 + 1) * hid + ch] = s2[e];
+      }
+    }
+  }
+  if (l4 == (l15 >> 2) && cw + l15 < hid) {  // D[c][c'] lives at (rows 4 l4 + e, column l15): the diagonal element of channel l15
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float v = (l15 & 3) == 0 ? dwa[t][0] : ((l15 & 3) == 1 ? dwa[t][1] : ((l15 & 3) == 2 ? dwa[t][2] : dwa[t][3]));
+      p.dw_part[(size_t)row_id * hid * 9 + (size_t)(cw + l15) * 9 + t] = v;
+    }
+  }
+}
+
+// (sum y1, sum y1^2) per expansion channel from the Gram matrix G = x^T x [K][Gp] and the column sums s = 1^T x of the narrow input:
+// y1 = x W1^T  =>  sum y1[c] = W1[c] . s,  sum y1[c]^2 = W1[c] G W1[c]^T.  One workgroup per channel; double accumulation (the
+// quadratic form cancels when the terms of y1 do).  Output = one partial-statistics row [2][hid] for cvh_bn_finalize.
+__global__ __launch_bounds__(128) void gram_bn_stats_kernel(const float* __restrict__ G, const float* __restrict__ s, const bf16_t* __restrict__ w1,
+                                                            float* __restrict__ part, int hid, int K, int Gp) {
+  __shared__ float wsh[128];
+  __shared__ double red[2][128];
+  const int c = blockIdx.x, i = threadIdx.x;
+  wsh[i] = i < K ? bf2f(w1[(size_t)c * K + i].v) : 0.f;
+  __syncthreads();
+  double m = 0.0, q = 0.0;
+  if (i < K) {
+    double r = 0.0;
+    for (int j = 0; j < K; ++j) r += (double)G[(size_t)j * Gp + i] * (double)wsh[j];  // G is symmetric: column i read along a row
+    q = (double)wsh[i] * r;
+    m = (double)wsh[i] * (double)s[i];
+  }
+  red[0][i] = m;
+  red[1][i] = q;
+  __syncthreads();
+  for (int st = 64; st > 0; st >>= 1) {
+    if (i < st) {
+      red[0][i] += red[0][i + st];
+      red[1][i] += red[1][i + st];
+    }
+    __syncthreads();
+  }
+  if (i == 0) {
+    part[c] = (float)red[0][0];
+    part[hid + c] = (float)red[1][0];
+  }
+}
+
+template <int S, int CIN> size_t dwx_fwd_smem() {
+  using TL = DxTile<S>;
+  constexpr int NPB = (TL::IH * TL::IW + 15) / 16;
+  return (size_t)NPB * 16 * (32 * ((CIN + 31) / 32) + 8 + DX_AP) * 2;
+}
+
+template <int S, int CIN> size_t dwx_bwd_smem() {
+  return ((size_t)(DxBwd<S>::DH * DxBwd<S>::DW + 128) * DX_AP + (size_t)128 * (32 * ((CIN + 31) / 32) + 8)) * 2 + 7 * DX_CC * 4;
+}
+
+bool dwx_cin_ok(int Cin) { return Cin == 16 || Cin == 32 || Cin == 64 || Cin == 96 || Cin == 128; }
+
+int dwx_plan(int B, int Ho, int Wo, int hid, int stride, int* tiles_h, int* tiles_w, int* chunks) {
+  const int OH = stride == 1 ? 8 : 4, OW = stride == 1 ? 16 : 8;
+  *tiles_h = (Ho + OH - 1) / OH;
+  *tiles_w = (Wo + OW - 1) / OW;
+  *chunks = (hid + DX_CC - 1) / DX_CC;
+  const long long ntiles = (long long)B * *tiles_h * *tiles_w;
+  int rows = 2048 / *chunks;  // ~2048 workgroups in XCD-contiguous round-robin order; partial-statistics rows <= 512
+  if (rows > 512) rows = 512;
+  if (rows < 32) rows = 32;
+  if (rows > ntiles) rows = (int)ntiles;
+  return rows;
+}
+
+}  // namespace
+
+/* rows of the partial-statistics / partial-dW buffers of cvh_dwx_fwd / cvh_dwx_bwd (= workgroups per 64-channel chunk) */
+extern "C" int cvh_dwx_rows(int B, int Ho, int Wo, int hid, int stride) {
+  if (B <= 0 || hid <= 0 || (hid % 8) || (stride != 1 && stride != 2)) return -2;
+  int th, tw, ch;
+  return dwx_plan(B, Ho, Wo, hid, stride, &th, &tw, &ch);
+}
+
+extern "C" int cvh_gram_bn_stats(const float* G, const float* s, const void* w1, float* part, int hid, int K, int Gp, void* stream) {
+  if (K <= 0 || K > 128 || hid <= 0) return -2;
+  hipLaunchKernelGGL(gram_bn_stats_kernel, dim3(hid), dim3(128), 0, (hipStream_t)stream, G, s, reinterpret_cast<const bf16_t*>(w1), part, hid, K,
+                     Gp);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int cvh_dwx_fwd(int dtype, const void* x, const void* w1, const float* scale1, const float* shift1, int act1, const void* wd, void* y2,
+                           float* stats_part, int B, int H, int W, int Ho, int Wo, int Cin, int hid, int stride, void* stream) {
+  if (dtype != CVH_DT_BF16) return -1;
+  if (act1 != CVH_ACT_SILU) return -2;
+  if (!dwx_cin_ok(Cin) || (stride == 1 && Cin > 64) || hid <= 0 || (hid % 8) || (stride != 1 && stride != 2)) return -2;
+  if (Ho != (H + 2 - 3) / stride + 1 || Wo != (W + 2 - 3) / stride + 1) return -2;
+  if (B <= 0) return 0;
+  DwxFwdParams p;
+  p.x = reinterpret_cast<const bf16_t*>(x); p.w1 = reinterpret_cast<const bf16_t*>(w1); p.scale1 = scale1; p.shift1 = shift1;
+  p.wd = reinterpret_cast<const bf16_t*>(wd); p.y2 = reinterpret_cast<bf16_t*>(y2); p.stats_part = stats_part; p.act1 = act1;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.hid = hid;
+  const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
+  p.ntiles = B * p.tiles_h * p.tiles_w;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(rows * p.chunks);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+#define DX_FWD(S_, C_)                                                                                                                    \
+  do {                                                                                                                                    \
+    const size_t smem = dwx_fwd_smem<S_, C_>();                                                                                           \
+    static unsigned attr_done = 0; /* one bit per device: the attribute is per device */                                                  \
+    if (smem > 64 * 1024 && !((attr_done >> (dev & 31)) & 1u)) {                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwx_fwd_kernel<S_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)smem);                                                                                      \
+      if (e != hipSuccess) return (int)e;                                                                                                 \
+      attr_done |= 1u << (dev & 31);                                                                                                      \
+    }                                                                                                                                     \
+    hipLaunchKernelGGL((dwx_fwd_kernel<S_, C_>), grid, dim3(256), smem, st, p);                                                           \
+  } while (0)
+#define DX_FWD_S(C_)              \
+  do {                            \
+    if (stride == 1) DX_FWD(1, C_); \
+    else DX_FWD(2, C_);           \
+  } while (0)
+  switch (Cin) {
+    case 16: DX_FWD_S(16); break;
+    case 32: DX_FWD_S(32); break;
+    case 64: DX_FWD_S(64); break;
+    case 96: DX_FWD_S(96); break;
+    default: DX_FWD_S(128); break;
+  }
+#undef DX_FWD_S
+#undef DX_FWD
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float* in_stats, int act1, const void* g_out, const void* y_out,
+                           const float* ca, const float* cb, const float* cc, const void* wd, void* g_in, float* stats_part, float* dw_part,
+                           int B, int H, int W, int Ho, int Wo, int Cin, int hid, int stride, void* stream) {
+  if (dtype != CVH_DT_BF16) return -1;
+  if (act1 != CVH_ACT_SILU) return -2;
+  if (!dwx_cin_ok(Cin) || (stride == 1 && Cin > 64) || hid <= 0 || (hid % 8) || (stride != 1 && stride != 2)) return -2;
+  if (Ho != (H + 2 - 3) / stride + 1 || Wo != (W + 2 - 3) / stride + 1) return -2;
+  if (in_stats == nullptr || stats_part == nullptr || dw_part == nullptr) return -2;
+  if (y_out != nullptr && (ca == nullptr || cb == nullptr || cc == nullptr)) return -2;
+  if (B <= 0) return 0;
+  DwxBwdParams p;
+  p.x = reinterpret_cast<const bf16_t*>(x); p.w1 = reinterpret_cast<const bf16_t*>(w1); p.in_stats = in_stats; p.act1 = act1;
+  p.g_out = reinterpret_cast<const bf16_t*>(g_out); p.y_out = reinterpret_cast<const bf16_t*>(y_out); p.ca = ca; p.cb = cb; p.cc = cc;
+  p.wd = reinterpret_cast<const bf16_t*>(wd); p.g_in = reinterpret_cast<bf16_t*>(g_in); p.stats_part = stats_part; p.dw_part = dw_part;
+  p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.hid = hid;
+  const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
+  p.ntiles = B * p.tiles_h * p.tiles_w;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(rows * p.chunks);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+#define DX_BWD(S_, C_)                                                                                                                    \
+  do {                                                                                                                                    \
+    const size_t smem = dwx_bwd_smem<S_, C_>();                                                                                           \
+    static unsigned attr_done = 0; /* one bit per device: the attribute is per device */                                                  \
+    if (smem > 64 * 1024 && !((attr_done >> (dev & 31)) & 1u)) {                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwx_bwd_kernel<S_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)smem);                                                                                      \
+      if (e != hipSuccess) return (int)e;                                                                                                 \
+      attr_done |= 1u << (dev & 31);                                                                                                      \
+    }                                                                                                                                     \
+    hipLaunchKernelGGL((dwx_bwd_kernel<S_, C_>), grid, dim3(256), smem, st, p);                                                           \
+  } while (0)
+#define DX_BWD_S(C_)              \
+  do {                            \
+    if (stride == 1) DX_BWD(1, C_); \
+    else DX_BWD(2, C_);           \
+  } while (0)
+  switch (Cin) {
+    case 16: DX_BWD_S(16); break;
+    case 32: DX_BWD_S(32); break;
+    case 64: DX_BWD_S(64); break;
+    case 96: DX_BWD_S(96); break;
+    default: DX_BWD_S(128); break;
+  }
+#undef DX_BWD_S
+#undef DX_BWD
+  CVH_CHECK_LAUNCH();
+  return 0;
+}

@@ -34,6 +34,10 @@ SIGNATURES = {
     "cvh_stream_counters": [I, P],  # out = long long[4]
     "cvh_stem_rows": [I, I, I, I],
     "cvh_ir_exp_bwd_rows": [L, I, I],
+    "cvh_dwx_rows": [I, I, I, I, I],
+    "cvh_gram_bn_stats": [P, P, P, P, I, I, I, P],
+    "cvh_dwx_fwd": [I, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P],
+    "cvh_dwx_bwd": [I, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     "cvh_ir_red_fwd_rows": [L, I, I],
     "cvh_ir_red_fwd": [I, P, P, P, I, P, P, P, L, I, I, P],
     "cvh_ir_exp_bwd": [I, P, P, P, P, P, P, P, L, I, I, P],

@@ -4,9 +4,13 @@ utils/ddp_utils.py:47-89 (same contract: ``.module``, parameters/buffers broadca
 
 Design for the 8-GPU xGMI mesh (7 links x ~153 GB/s per GPU, point-to-point):
   * every parameter gradient lives in a FLAT fp32 bucket (``p.grad`` is a view), so a bucket is one contiguous RCCL
-    message — few, large collectives (MobileViT-S: 22.3 MB = 1 bucket at the default 25 MB cap; ViT-B: 14 buckets);
+    message — few, large collectives.  Bucket sizes follow what the xGMI mesh needs, not torch's 25 MB: an 8 MB message already runs
+    at link bandwidth (~80 us over 7 x 153 GB/s links against ~20 us of launch latency), and the FIRST bucket is capped at 1 MB so that
+    the exchange starts as soon as the classifier's gradients exist (MobileViT-S, 22.3 MB: 4 buckets of 1 / 8 / 8 / 5.3 MB; ViT-B: 45);
   * buckets are filled in reverse-registration order (≈ autograd order); when the last gradient of a bucket has been
-    accumulated its all-reduce is enqueued on a SIDE HIP stream behind an event, overlapping the rest of backward;
+    accumulated its all-reduce is enqueued on a SIDE HIP stream behind an event, overlapping the rest of backward — also inside a
+    hipGraph capture (bench.py: the hooks run while the step is captured, so the fork / join around every bucket are graph edges and the
+    replayed step overlaps by construction); ``overlap_report()`` says how many buckets started before the end of backward;
   * ``finish`` (queued as an autograd end-of-backward callback) makes the compute stream wait for the side stream; the mean is taken
     by the collective itself (``ReduceOp.AVG`` on RCCL; gloo, which has no AVG, divides afterwards — CPU tests only);
   * with hipGraph-captured steps (bench.py) hooks do not fire on replay, so ``allreduce_flat`` runs the same buckets
@@ -78,8 +82,8 @@ class _Bucket:
 
 
 class DistributedDataParallel(nn.Module):
-    def __init__(self, module: nn.Module, bucket_cap_mb: float = 25.0, overlap: bool = True, broadcast_buffers: bool = True,
-                 process_group=None, force_collectives: Optional[bool] = None):
+    def __init__(self, module: nn.Module, bucket_cap_mb: float = 8.0, overlap: bool = True, broadcast_buffers: bool = True,
+                 process_group=None, force_collectives: Optional[bool] = None, first_bucket_mb: float = 1.0):
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -115,14 +119,15 @@ class DistributedDataParallel(nn.Module):
         self._avg_op = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(self.pg) == "nccl") else None
         # buckets in reverse registration order: the last layers' gradients are ready first
         cap = int(bucket_cap_mb * 1024 * 1024 / 4)
+        first_cap = min(cap, int(first_bucket_mb * 1024 * 1024 / 4))
         self.buckets: List[_Bucket] = []
         cur, cur_n = [], 0
-        for p in reversed(params):
-            if cur and cur_n + p.numel() > cap:
-                self.buckets.append(_Bucket(cur, self.device))
-                cur, cur_n = [], 0
+        for p in reversed(params):  # a bucket closes once it HOLDS its cap (a lone bias in front of a large weight is not a message)
             cur.append(p)
             cur_n += p.numel()
+            if cur_n >= (cap if self.buckets else first_cap):
+                self.buckets.append(_Bucket(cur, self.device))
+                cur, cur_n = [], 0
         if cur:
             self.buckets.append(_Bucket(cur, self.device))
         self._bucket_of = {}
@@ -132,9 +137,12 @@ class DistributedDataParallel(nn.Module):
                 p.register_post_accumulate_grad_hook(self._hook)
         self._callback_task = None  # autograd graph-task id whose end-of-backward `finish` is queued (a dropped callback cannot go stale)
         self.hooks_enabled = True
+        self.early_launches = 0   # buckets whose all-reduce started from a hook, i.e. before the end of backward (overlapped)
+        self.late_launches = 0    # buckets that `finish` / `allreduce_flat` had to launch (no overlap: e.g. a parameter without gradient)
+        self._warned_no_overlap = False
         self._buf_span = None
         if self.flat_buffers is not None and fbufs:
-            self._buf_span = (fbufs[0], fbufs[-1])
+            self._buf_span = tuple(fbufs)  # every re-pointed buffer is checked before the flat broadcast (a partial .float() / re-registration)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -162,6 +170,7 @@ class DistributedDataParallel(nn.Module):
         b = self._bucket_of[p]
         b.pending -= 1
         if b.pending == 0 and self.overlap:
+            self.early_launches += 1
             self._launch(b)
 
     def _launch(self, b: _Bucket):
@@ -183,9 +192,19 @@ class DistributedDataParallel(nn.Module):
 
     def finish(self):
         """end of backward: launch whatever was not launched, wait, average."""
+        late = 0
         for b in self.buckets:
             if b.work is None:
+                late += 1
                 self._launch(b)
+        self.late_launches += late
+        if late and self.overlap and len(self.buckets) > 1 and late == len(self.buckets) and not self._warned_no_overlap:
+            # every bucket waited for the end of backward: some parameter of each bucket produced no gradient (the
+            # find_unused_parameters case of main_train.py:95) — results are correct, nothing overlapped; say so once
+            self._warned_no_overlap = True
+            import warnings
+            warnings.warn("cvnets_amd.ddp: no gradient bucket was complete before the end of backward (parameters without gradients?): "
+                          "the all-reduce did not overlap with backward")
         for b in self.buckets:
             b.work.wait()
             b.work = None
@@ -194,6 +213,37 @@ class DistributedDataParallel(nn.Module):
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         self._average()
         self._callback_task = None
+
+    def overlap_report(self) -> dict:
+        """how the gradient exchange has been scheduled so far: buckets, their sizes, launches before / at the end of backward"""
+        return {"buckets": len(self.buckets), "bucket_mb": [round(b.numel * 4 / 2 ** 20, 2) for b in self.buckets],
+                "launched_during_backward": self.early_launches, "launched_at_end_of_backward": self.late_launches}
+
+    # ---- copies (EMA does deepcopy(model) on the WRAPPED model, cvnets/misc/averaging_utils.py:33; torch.save(model) pickles it) ----
+    # A copy is a passive holder of a copy of `.module`: no process group, no side stream (HIP streams cannot be copied or pickled), no
+    # buckets, no hooks — exactly what the reference needs from it (`.module`, parameters(), state_dict(), eval()).
+    def _passive_copy(self, module: nn.Module) -> "DistributedDataParallel":
+        new = DistributedDataParallel.__new__(DistributedDataParallel)
+        nn.Module.__init__(new)
+        new.module = module
+        new.pg, new.world, new.active, new.overlap, new.broadcast_buffers = None, 1, False, False, False
+        new.device = self.device
+        new.use_side_stream, new.side_stream, new.flat_buffers, new._buf_span = False, None, None, None
+        new._avg_op, new.buckets, new._bucket_of = None, [], {}
+        new._callback_task, new.hooks_enabled = None, False
+        new.early_launches = new.late_launches = 0
+        new._warned_no_overlap = True
+        new.training = self.training
+        return new
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self._passive_copy(copy.deepcopy(self.module, memo))
+        memo[id(self)] = new
+        return new
+
+    def __reduce__(self):
+        return (_rebuild_passive, (self.module, self.training))
 
     # ---- explicit path (after a hipGraph replay) ---------------------------------------------
     def allreduce_flat(self):
@@ -235,6 +285,15 @@ class DistributedDataParallel(nn.Module):
                     if b.dtype.is_floating_point:
                         dist.broadcast(b.data, src=0, group=self.pg)
         return self.module(*args, **kwargs)
+
+
+def _rebuild_passive(module: nn.Module, training: bool) -> DistributedDataParallel:
+    new = DistributedDataParallel.__new__(DistributedDataParallel)
+    nn.Module.__init__(new)
+    new.device = next(module.parameters()).device
+    new = DistributedDataParallel._passive_copy(new, module)
+    new.training = training
+    return new
 
 
 class _AllGatherWithGrad(torch.autograd.Function):

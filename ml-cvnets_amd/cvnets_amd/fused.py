@@ -24,6 +24,9 @@ from .ops import ACT_NONE, _dt, _f32, _p, _stream
 
 _IR_EXP_FUSED = __import__("os").environ.get("CVH_IR_EXP_FUSED", "1") != "0"
 _IR_RED_FUSED = __import__("os").environ.get("CVH_IR_RED_FUSED", "1") != "0"
+# expansion + depthwise as ONE kernel per direction with y1 recomputed from the narrow input (csrc/dwx.hip): 0 = off, 1 = forward and
+# backward, "fwd" = forward only (the backward then rebuilds y1 with the expansion GEMM and runs cvh_dwconv_bn_bwd: A/B runs, tests)
+_IR_X = __import__("os").environ.get("CVH_IR_X", "1")
 DW_SHAPE_LOG = None  # set to a list to record the plain dW GEMMs launched from this module (bench.py)
 
 
@@ -88,7 +91,30 @@ def _pw_weight_grad(dy, dy_xf_args, x, x_xf_args, weight, M, N, K):
     return dw
 
 
-def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp, P_ready=None):
+def _dwx_eligible(dt, Cin, w1, hid, stride, act1) -> bool:
+    """shapes cvh_dwx_fwd / cvh_dwx_bwd cover (bf16; SiLU; unpadded input channels; stride 1 up to 64 input channels)"""
+    return (_IR_X != "0" and dt == torch.bfloat16 and act1 == ops.ACT_SILU and w1.shape[1] == Cin and Cin in (16, 32, 64, 96, 128)
+            and not (stride == 1 and Cin > 64) and hid % 8 == 0)
+
+
+def _gram(x, M, Kp):
+    """G = x^T x [Kp][Kp] and s = 1^T x [Kp] of a narrow [M][Kp] tensor (float32): one cvh_gemm_dw + one cvh_colsum"""
+    dev = x.device
+    if DW_SHAPE_LOG is not None:
+        DW_SHAPE_LOG.append((int(M), 1, 1, 1, 1, int(Kp), 0, 1, 1, 1, 0, 1, int(Kp), int(Kp)))
+    G = torch.empty(Kp * Kp, dtype=torch.float32, device=dev)
+    n_scr = _lib.query("cvh_gemm_dw_scratch_elems", int(M), int(Kp), int(Kp))
+    scr = _f32(max(n_scr, 1), dev)
+    _lib.call("cvh_gemm_dw", _dt(x), _p(x), _p(x), None, Kp, 0, _p(G), int(M), 1, 1, 1, 1, 1, 1, 1, 0, 1, int(Kp), int(Kp), _p(scr), n_scr, 0,
+              _stream())
+    R = _lib.query("cvh_colreduce_rows", int(M), int(Kp))
+    part = _f32(R * 2 * Kp, dev)
+    s_ = _f32(Kp, dev)
+    _lib.call("cvh_colsum", _dt(x), _p(x), int(M), int(Kp), _p(part), _p(s_), 1.0, 0, _stream())
+    return G, s_
+
+
+def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp, P_ready=None, gram=None):
     """dW of a 1x1 conv y = x W^T that sits in front of a train-mode BatchNorm, from g = dz * act'(bn(y)) and the backward coefficients
     coef[3][N] of that BatchNorm:  dW = diag(ca) (g^T x) + diag(cb) W (x^T x) + cc (1^T x)  — y is not read (csrc/bnlink.hip)."""
     sink = ops._grad_sink(weight)
@@ -106,17 +132,20 @@ def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp, P_ready=None):
                       _p(scr), n_scr, 0, _stream())
             return out
         P = P_ready if P_ready is not None else gemm_dw(g, N, Kr)      # g^T x   [N][Kr]
-        G = gemm_dw(x, Kp, Kp)     # x^T x   [Kp][Kp]
-        R = _lib.query("cvh_colreduce_rows", int(M), int(Kp))
-        part = _f32(R * 2 * Kp, dev)
-        s_ = _f32(Kp, dev)
-        _lib.call("cvh_colsum", _dt(x), _p(x), int(M), int(Kp), _p(part), _p(s_), 1.0, 0, _stream())
+        if gram is not None:       # the forward pass already formed them for the BatchNorm statistics (csrc/dwx.hip)
+            G, s_ = gram
+        else:
+            G = gemm_dw(x, Kp, Kp)     # x^T x   [Kp][Kp]
+            R = _lib.query("cvh_colreduce_rows", int(M), int(Kp))
+            part = _f32(R * 2 * Kp, dev)
+            s_ = _f32(Kp, dev)
+            _lib.call("cvh_colsum", _dt(x), _p(x), int(M), int(Kp), _p(part), _p(s_), 1.0, 0, _stream())
         _lib.call("cvh_bn_dw_combine", _p(P), _p(weight), _p(G), _p(s_), _p(coef), _p(dw), int(N), int(Kr), accumulate, _stream())
 
     side = ops._param_grad_stream(dev) if (sink is not None and P_ready is None) else None
     if side is not None:
         with torch.cuda.stream(side):
-            for t in (g, x, coef):
+            for t in (g, x, coef) + (tuple(gram) if gram is not None else ()):
                 t.record_stream(side)
             launch(sink, 1)
         return None
@@ -149,17 +178,35 @@ class InvertedResidualFn(torch.autograd.Function):
                           _stream())
                 sts.append(st)
             st1, st2, st3 = sts
-        y1 = ops.nhwc_empty(B, hid, H, W, dt, dev)
-        part, R = _pw_gemm(x, None, Cin, wp1, y1, M1, hid, want_stats=training)
-        if training:
-            st1 = ops._bn_forward(y1, M1, hid, part, R, g1, b1, rm1, rv1, True, mom[0], eps[0])
+        use_x = _dwx_eligible(dt, Cin, w1, hid, stride, act1)
         y2 = ops.nhwc_empty(B, hid, Ho, Wo, dt, dev)
-        part, R = None, 0
-        if training:
-            R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
-            part = _f32(R * 2 * hid, dev)
-        _lib.call("cvh_dwconv_bn_fwd", _dt(x), _p(y1), _xf(1, None, st1[2], st1[3], None, act1), _p(wpd), _p(y2), B, H, W, Ho, Wo, hid,
-                  stride, _p(part), _stream())
+        gram = None
+        if use_x:
+            # y1 = x W1^T never exists in HBM: BatchNorm statistics of the expansion from the Gram matrix of the narrow input (y1 is linear
+            # in x), expansion + BN + act + depthwise conv in one kernel (csrc/dwx.hip)
+            y1 = None
+            if training:
+                gram = _gram(x, M1, Cin)
+                part = _f32(2 * hid, dev)
+                _lib.call("cvh_gram_bn_stats", _p(gram[0]), _p(gram[1]), _p(wp1), _p(part), hid, Cin, Cin, _stream())
+                st1 = ops._bn_forward(x, M1, hid, part, 1, g1, b1, rm1, rv1, True, mom[0], eps[0])
+            part, R = None, 0
+            if training:
+                R = _lib.query("cvh_dwx_rows", B, Ho, Wo, hid, stride)
+                part = _f32(R * 2 * hid, dev)
+            _lib.call("cvh_dwx_fwd", _dt(x), _p(x), _p(wp1), _p(st1[2]), _p(st1[3]), act1, _p(wpd), _p(y2), _p(part), B, H, W, Ho, Wo, Cin, hid,
+                      stride, _stream())
+        else:
+            y1 = ops.nhwc_empty(B, hid, H, W, dt, dev)
+            part, R = _pw_gemm(x, None, Cin, wp1, y1, M1, hid, want_stats=training)
+            if training:
+                st1 = ops._bn_forward(y1, M1, hid, part, R, g1, b1, rm1, rv1, True, mom[0], eps[0])
+            part, R = None, 0
+            if training:
+                R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
+                part = _f32(R * 2 * hid, dev)
+            _lib.call("cvh_dwconv_bn_fwd", _dt(x), _p(y1), _xf(1, None, st1[2], st1[3], None, act1), _p(wpd), _p(y2), B, H, W, Ho, Wo, hid,
+                      stride, _p(part), _stream())
         if training:
             st2 = ops._bn_forward(y2, M2, hid, part, R, g2, b2, rm2, rv2, True, mom[1], eps[1])
         y3 = ops.nhwc_empty(B, Cout, Ho, Wo, dt, dev)
@@ -177,14 +224,16 @@ class InvertedResidualFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.geom = (B, Cin, H, W, Ho, Wo, hid, Cout)
         ctx.params = (g1, b1, g2, b2, g3, b3)
-        ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3)
+        ctx.use_x = use_x
+        ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, *(gram if gram is not None else (None, None)))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         stride, use_res, training, act1, act2, mom, eps = ctx.cfg
         B, Cin, H, W, Ho, Wo, hid, Cout = ctx.geom
-        x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3 = ctx.saved_tensors
+        x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, gram_G, gram_s = ctx.saved_tensors
+        gram = (gram_G, gram_s) if gram_G is not None else None
         pg1, pb1, pg2, pb2, pg3, pb3 = ctx.params
         dout = ops.as_nhwc(dout)
         dev, dt = dout.device, dout.dtype
@@ -199,12 +248,24 @@ class InvertedResidualFn(torch.autograd.Function):
                            want_stats=True)
         coef2, dg2, db2 = _bwd_finalize(part, R, hid, M2, g2, st2, pg2, pb2, training)
         # depthwise backward in one pass: dy2 formed on load, g1 out, dW of the depthwise conv, statistics of g1
-        g1t = torch.empty_like(y1)
-        R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
-        part = _f32(R * 2 * hid, dev)
-        dw_part = _f32(R * hid * 9, dev)
-        _lib.call("cvh_dwconv_bn_bwd", _dt(g2t), _p(g2t), _xf(2, y2, coef2[0], coef2[1], coef2[2]), _p(y1), _p(st1), act1,
-                  _p(ops.pack_weight(wd, dt, 2)), _p(g1t), _p(part), _p(dw_part), B, H, W, Ho, Wo, hid, stride, _stream())
+        g1t = ops.nhwc_empty(B, hid, H, W, dt, dev)
+        if ctx.use_x and _IR_X != "fwd":
+            # y1 recomputed from x at the tile's own pixels; dX, dW and the statistics on the matrix pipe (csrc/dwx.hip)
+            R = _lib.query("cvh_dwx_rows", B, Ho, Wo, hid, stride)
+            part = _f32(R * 2 * hid, dev)
+            dw_part = _f32(R * hid * 9, dev)
+            wp1, wpd = ops.pack_weight(w1, dt, 0), ops.pack_weight(wd, dt, 2)  # both alive across the launch (uncached packs are temporaries)
+            _lib.call("cvh_dwx_bwd", _dt(g2t), _p(x), _p(wp1), _p(st1), act1, _p(g2t), _p(y2), _p(coef2[0]), _p(coef2[1]), _p(coef2[2]),
+                      _p(wpd), _p(g1t), _p(part), _p(dw_part), B, H, W, Ho, Wo, Cin, hid, stride, _stream())
+        else:
+            if y1 is None:  # forward ran without y1 (CVH_IR_X=fwd): rebuild it with the expansion GEMM
+                y1 = ops.nhwc_empty(B, hid, H, W, dt, dev)
+                _pw_gemm(x, None, Cin, ops.pack_weight(w1, dt, 0), y1, M1, hid)
+            R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
+            part = _f32(R * 2 * hid, dev)
+            dw_part = _f32(R * hid * 9, dev)
+            _lib.call("cvh_dwconv_bn_bwd", _dt(g2t), _p(g2t), _xf(2, y2, coef2[0], coef2[1], coef2[2]), _p(y1), _p(st1), act1,
+                      _p(ops.pack_weight(wd, dt, 2)), _p(g1t), _p(part), _p(dw_part), B, H, W, Ho, Wo, hid, stride, _stream())
         coef1, dg1, db1 = _bwd_finalize(part, R, hid, M1, g1, st1, pg1, pb1, training)
         sink = ops._grad_sink(wd)
         dwd = None if sink is not None else torch.empty(wd.shape, dtype=torch.float32, device=dev)
@@ -231,7 +292,7 @@ class InvertedResidualFn(torch.autograd.Function):
                 ops._conv_gemm(g1t, x, hid, Cin, wcat, dx, M1, 1, 1, 1, 1, 1, 1, 1, 0, 1, Cin, bias=bias, residual=dout if use_res else None)
         elif use_res:
             dx = dout
-        dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin, P_ready=P1)
+        dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin, P_ready=P1, gram=gram)
         return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None)
 
 

@@ -693,7 +693,11 @@ def stem_eligible(x, weight, bias, stride, pad, dil, use_bn, residual=None, x2=N
     return (_STEM_KERNEL and use_bn and bias is None and residual is None and x2 is None and x.dim() == 4 and x.shape[1] == 3
             and tuple(weight.shape[1:]) == (3, 3, 3) and weight.shape[0] in (16, 32) and (stride, pad, dil) == (2, 1, 1)
             and x.shape[3] % 4 == 0 and x.shape[2] >= 2 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
-            and not x.requires_grad and compute_dtype() == torch.bfloat16 and weight.dtype in (torch.float32, torch.bfloat16))
+            and not x.requires_grad and compute_dtype() == torch.bfloat16 and weight.dtype in (torch.float32, torch.bfloat16)
+            # the kernels read the weight (and add its gradient) as dense OIHW: a model moved to channels_last (launch.py does that for
+            # `common.channels_last`) has conv_1.weight strided (27, 1, 9, 3) — such a layer takes the repack + implicit-GEMM path, which
+            # goes through pack_weight's contiguous copy
+            and weight.is_contiguous() and (weight.grad is None or weight.grad.is_contiguous()))
 
 
 _STEM_KERNEL = os.environ.get("CVH_STEM_KERNEL", "1") != "0"

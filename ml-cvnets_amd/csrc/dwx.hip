@@ -66,23 +66,42 @@ struct DwxFwdParams {
   int act1;
   int B, H, W, Ho, Wo, hid;
   int tiles_h, tiles_w, ntiles, chunks;
+  int dbg;  // developer knob (CVH_TUNE key 17): skip phases to time them (results are WRONG when non-zero)
 };
 
+// LDS pitch of the x tiles: dense rows for one 32-wide K step (2-way conflicts on the operand reads, 4 workgroups per CU), + 16 B otherwise
+template <int CIN> __host__ __device__ constexpr int dx_xp() { return 32 * ((CIN + 31) / 32) + (CIN <= 32 ? 0 : 8); }
+// waves per SIMD the register allocator is held to (= workgroups per CU the LDS footprint allows)
+#ifndef DX_OCC_A
+#define DX_OCC_A 4
+#endif
+#ifndef DX_OCC_B
+#define DX_OCC_B 3
+#endif
+#ifndef DX_OCC16
+#define DX_OCC16 3
+#endif
+#ifndef DX_OCC64
+#define DX_OCC64 3
+#endif
+template <int CIN> __host__ __device__ constexpr int dx_fwd_occ() { return CIN <= 16 ? DX_OCC16 : (CIN <= 32 ? 3 : (CIN <= 64 ? DX_OCC64 : 2)); }
+
 template <int S, int CIN>
-__global__ __launch_bounds__(256, 2) void dwx_fwd_kernel(DwxFwdParams p) {
+__global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdParams p) {
   using TL = DxTile<S>;
-  constexpr int KS = (CIN + 31) / 32, XP = 32 * KS + 8, XC = CIN / 8;
+  constexpr int KS = (CIN + 31) / 32, XP = dx_xp<CIN>(), XC = CIN / 8;
   constexpr int NPIX = TL::IH * TL::IW, NPB = (NPIX + 15) / 16, NOB = TL::OH * TL::OW / 16;
   constexpr int NXL = (NPIX * XC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [NPB * 16][XP]   block input, tile + halo (zero outside the image / past CIN)
-  bf16_t* at = xs + NPB * 16 * XP;                   // [NPB * 16][DX_AP] act(bn1(y1)) of this workgroup's 64 channels
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [NPB * 16][XP]    block input, tile + halo (zero outside the image / past CIN)
+  bf16_t* at = xs + NPB * 16 * XP;                   // [4][NPB * 16][16] act(bn1(y1)): one dense [pixel][16 channels] image per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
   const int chunk = lb % p.chunks, row_id = lb / p.chunks;
   const int cw = chunk * DX_CC + 16 * wave;  // first channel of this wave
   const int hid = p.hid;
+  bf16_t* atw = at + wave * (NPB * 16 * 16);
 
   for (int i = tid; i < NPB * 16 * XP / 8; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
 
@@ -96,14 +115,28 @@ __global__ __launch_bounds__(256, 2) void dwx_fwd_kernel(DwxFwdParams p) {
   }
 #pragma unroll
   for (int tp = 0; tp < 5; ++tp) wdf[tp] = diag_frag(p.wd, hid, cw + l15, tp, l15, l4, false);
-  float sc[4], sh[4];
+  // BatchNorm coefficients of the lane's 4 channels as two packed pairs (the VALU is what bounds this kernel — a plain wave64 fp32
+  // instruction occupies it for 4 cycles, v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two lanes' worth in the same time); the exponent
+  // of the sigmoid gets its own pre-scaled pair: 2^(-yh log2 e) = exp2(nsc * y + nsh)
+  f32x2_t sc[2], sh[2], nsc[2], nsh[2];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int ch = cw + 4 * l4 + e;
-    sc[e] = ch < hid ? p.scale1[ch] : 0.f;
-    sh[e] = ch < hid ? p.shift1[ch] : 0.f;
+    const float a = ch < hid ? p.scale1[ch] : 0.f, c = ch < hid ? p.shift1[ch] : 0.f;
+    sc[e >> 1][e & 1] = a;
+    sh[e >> 1][e & 1] = c;
+    nsc[e >> 1][e & 1] = -1.4426950408889634f * a;
+    nsh[e >> 1][e & 1] = -1.4426950408889634f * c;
   }
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2_t s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  // tile-independent parts of the output addressing (elements): lane offset of output block ob from the tile's first output pixel
+  // (output block ob of a lane: row ob (stride 1) / 2 ob + l15 / 8 (stride 2) -> offset = yoff0 + ob * ystep)
+  const int yoff0 = ((S == 1 ? 0 : (l15 >> 3)) * p.Wo + (S == 1 ? l15 : (l15 & 7))) * hid + cw + 4 * l4;
+  const int ystep = (S == 1 ? 1 : 2) * p.Wo * hid;
+  const bool wave_full = cw + 16 <= hid;  // all 16 channels of this wave exist
+  uint32_t vm_in = 0;                      // halo-tile pixels of this lane that exist at all (the last block overhangs the tile)
+#pragma unroll
+  for (int pb = 0; pb < (TL::IH * TL::IW + 15) / 16; ++pb) vm_in |= ((16 * pb + l15 < TL::IH * TL::IW) ? 1u : 0u) << pb;
 
   // LDS offsets (elements) of the lane's B-operand reads in the stencil phase: tap (2 tp + slot), clamped to a real tap for the idle slot
   int toff[5];
@@ -111,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void dwx_fwd_kernel(DwxFwdParams p) {
   for (int tp = 0; tp < 5; ++tp) {
     int tap = 2 * tp + (l4 >> 1);
     tap = tap > 8 ? 8 : tap;
-    toff[tp] = ((tap / 3) * TL::IW + (tap % 3)) * DX_AP + 16 * wave + 8 * (l4 & 1);
+    toff[tp] = ((tap / 3) * TL::IW + (tap % 3)) * 16 + 8 * (l4 & 1);
   }
 
   const int t_step = gridDim.x / p.chunks;
@@ -154,76 +187,131 @@ __global__ __launch_bounds__(256, 2) void dwx_fwd_kernel(DwxFwdParams p) {
       }
     }
     __syncthreads();
-    if (tix + t_step < p.ntiles) load_x(tix + t_step);  // next tile's input, in flight under this tile's arithmetic
+    if (tix + t_step < p.ntiles && !(p.dbg & 16)) load_x(tix + t_step);  // next tile's input, in flight under this tile's arithmetic
 
-    // pixels of the halo tile that lie inside the image (the conv's zero padding applies to the ACTIVATED tensor)
-    uint32_t vmask = 0;
+    // pixels of the halo tile that lie inside the image (the conv's zero padding applies to the ACTIVATED tensor); interior tiles —
+    // a wave-uniform test — skip the per-pixel arithmetic
+    uint32_t vmask = vm_in;
+    if (hi0 < 0 || wi0 < 0 || hi0 + TL::IH > p.H || wi0 + TL::IW > p.W) {
+      vmask = 0;
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-      const int px = 16 * pb + l15;
-      const int pr = px / TL::IW, pc = px - pr * TL::IW;
-      const int hi = hi0 + pr, wi = wi0 + pc;
-      vmask |= ((px < NPIX && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) ? 1u : 0u) << pb;
+      for (int pb = 0; pb < NPB; ++pb) {
+        const int px = 16 * pb + l15;
+        const int pr = px / TL::IW, pc = px - pr * TL::IW;
+        const int hi = hi0 + pr, wi = wi0 + pc;
+        vmask |= ((px < NPIX && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) ? 1u : 0u) << pb;
+      }
     }
 
     // ---- expansion + BatchNorm + activation -> activation tile (this wave's 16 channels of every pixel) ----
+    // Software pipeline over the 16-pixel blocks, written out: the operand reads of block pb + 1 are issued BEFORE the epilogue of block
+    // pb - 1 stores to LDS (the compiler cannot hoist an LDS read above an LDS store it cannot disambiguate, and a wave that waits
+    // for its reads, then for its MFMAs, then runs its epilogue, leaves the SIMD idle two thirds of the time at 2-4 waves per SIMD),
+    // and the MFMAs of block pb run under the VALU work of block pb - 1.
+    if (!(p.dbg & 4)) {
+      bf16x8_t bq[KS];
+      auto rd = [&](int pb) __attribute__((always_inline)) {
+        const bf16_t* xrow = xs + (16 * pb + l15) * XP + 8 * l4;
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb) {
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      const bf16_t* xrow = xs + (16 * pb + l15) * XP + 8 * l4;
+        for (int ks = 0; ks < KS; ++ks) bq[ks] = *reinterpret_cast<const bf16x8_t*>(xrow + 32 * ks);
+      };
+      // SiLU(bn(y1)) of 4 channels in 2 x (2 v_pk_fma, 2 v_exp, v_pk_add, 2 v_rcp, v_pk_mul, v_cvt_pk) — SiLU is the only activation
+      // these kernels are compiled for (a run-time dispatch per element cuts the unrolled epilogues into blocks the scheduler cannot
+      // interleave); y1 enters in fp32 (it is never a tensor here, so nothing rounds it)
+      auto epi = [&](int pb, const f32x4_t& acc) __attribute__((always_inline)) {
+        uint32_t w[2];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma16(w1f[ks], *reinterpret_cast<const bf16x8_t*>(xrow + 32 * ks), acc);
-      float v[4];
+        for (int h = 0; h < 2; ++h) {
+          const f32x2_t y = {acc[2 * h], acc[2 * h + 1]};
+          const f32x2_t yh = sc[h] * y + sh[h];
+          const f32x2_t t = nsc[h] * y + nsh[h];
+          f32x2_t d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+          d = d + 1.0f;
+          const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+          const f32x2_t v = yh * r;
+          w[h] = f2bf_pk(v[0], v[1]);
+        }
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vmask, pb, 1);  // all ones inside the image, zero outside
+        *reinterpret_cast<uint2*>(atw + (16 * pb + l15) * 16 + 4 * l4) = make_uint2(w[0] & m, w[1] & m);
+      };
+      f32x4_t accp = {0.f, 0.f, 0.f, 0.f};
+      rd(0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float yh = sc[e] * rbf(acc[e]) + sh[e];  // y1 as it would read back from a bf16 tensor
-        v[e] = yh * sigmoidf_(yh);                      // SiLU (the only activation these kernels are compiled for: a run-time dispatch per
-                                                        // element cuts the unrolled epilogues into basic blocks the scheduler cannot interleave)
+      for (int pb = 0; pb < NPB; ++pb) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma16(w1f[ks], bq[ks], acc);
+        if (pb + 1 < NPB) rd(pb + 1);
+        if (pb > 0) epi(pb - 1, accp);
+        accp = acc;
       }
-      if (!((vmask >> pb) & 1u)) v[0] = v[1] = v[2] = v[3] = 0.f;
-      *reinterpret_cast<uint2*>(at + (16 * pb + l15) * DX_AP + 16 * wave + 4 * l4) = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+      epi(NPB - 1, accp);
     }
     wave_lds_sync();
 
-    // ---- depthwise stencil on the matrix pipe ----
+    // ---- depthwise stencil on the matrix pipe (two accumulators: the five products of a block are not one dependent chain) ----
+    if (!(p.dbg & 8)) {
+      bf16x8_t fq[5];
+      auto rd = [&](int ob) __attribute__((always_inline)) {
+        const int orow = S == 1 ? ob : 2 * ob + (l15 >> 3), ocol = S == 1 ? l15 : (l15 & 7);
+        const bf16_t* base = atw + ((orow * S) * TL::IW + ocol * S) * 16;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-      const int orow = S == 1 ? ob : 2 * ob + (l15 >> 3), ocol = S == 1 ? l15 : (l15 & 7);
-      const bf16_t* base = at + ((orow * S) * TL::IW + ocol * S) * DX_AP;
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tp = 0; tp < 5; ++tp) acc = mfma16(wdf[tp], *reinterpret_cast<const bf16x8_t*>(base + toff[tp]), acc);
-      const int ho = ho0 + orow, wo = wo0 + ocol, ch = cw + 4 * l4;
-      if (ho < p.Ho && wo < p.Wo && ch < hid) {
-        const uint2 pk = make_uint2(f2bf_pk(acc[0], acc[1]), f2bf_pk(acc[2], acc[3]));
-        *reinterpret_cast<uint2*>(p.y2 + (((size_t)b * p.Ho + ho) * p.Wo + wo) * hid + ch) = pk;
-        const float q[4] = {bf2f((uint16_t)(pk.x & 0xffff)), bf2f((uint16_t)(pk.x >> 16)), bf2f((uint16_t)(pk.y & 0xffff)),
-                            bf2f((uint16_t)(pk.y >> 16))};  // statistics of the values as stored
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s1[e] += q[e];
-          s2[e] += q[e] * q[e];
+        for (int tp = 0; tp < 5; ++tp) fq[tp] = *reinterpret_cast<const bf16x8_t*>(base + toff[tp]);
+      };
+      // results leave as 8-byte stores from the accumulator layout: tile base (wave-uniform) + the lane's precomputed offset; statistics
+      // from the fp32 accumulators; tiles that overhang the image or a partial channel block take the checked path
+      bf16_t* ybase = p.y2 + (((size_t)b * p.Ho + ho0) * p.Wo + wo0) * hid;
+      const bool fast = wave_full && ho0 + TL::OH <= p.Ho && wo0 + TL::OW <= p.Wo && !(p.dbg & 2);
+      auto epi = [&](int ob, const f32x2_t& lo, const f32x2_t& hi2) __attribute__((always_inline)) {
+        bool ok = true;
+        if (!fast) {
+          const int orow = S == 1 ? ob : 2 * ob + (l15 >> 3), ocol = S == 1 ? l15 : (l15 & 7);
+          ok = ho0 + orow < p.Ho && wo0 + ocol < p.Wo && cw + 4 * l4 < hid && !(p.dbg & 2);
         }
+        if (ok) {
+          *reinterpret_cast<uint2*>(ybase + yoff0 + ob * ystep) = make_uint2(f2bf_pk(lo[0], lo[1]), f2bf_pk(hi2[0], hi2[1]));
+          s1[0] += lo;
+          s1[1] += hi2;
+          s2[0] += lo * lo;
+          s2[1] += hi2 * hi2;
+        }
+      };
+      f32x2_t plo = {0.f, 0.f}, phi = {0.f, 0.f};
+      rd(0);
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        a = mfma16(wdf[0], fq[0], a);
+        c = mfma16(wdf[1], fq[1], c);
+        a = mfma16(wdf[2], fq[2], a);
+        c = mfma16(wdf[3], fq[3], c);
+        a = mfma16(wdf[4], fq[4], a);
+        if (ob + 1 < NOB) rd(ob + 1);
+        if (ob > 0) epi(ob - 1, plo, phi);
+        plo = f32x2_t{a[0], a[1]} + f32x2_t{c[0], c[1]};
+        phi = f32x2_t{a[2], a[3]} + f32x2_t{c[2], c[3]};
       }
+      epi(NOB - 1, plo, phi);
     }
   }
 
   if (p.stats_part != nullptr) {
     // a lane's 4 channels are shared with the 15 other pixel lanes of its group: fixed butterfly, then one lane per group writes
+    float t1[4] = {s1[0][0], s1[0][1], s1[1][0], s1[1][1]}, t2[4] = {s2[0][0], s2[0][1], s2[1][0], s2[1][1]};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) {
-        s1[e] += __shfl_xor(s1[e], m, 64);
-        s2[e] += __shfl_xor(s2[e], m, 64);
+        t1[e] += __shfl_xor(t1[e], m, 64);
+        t2[e] += __shfl_xor(t2[e], m, 64);
       }
     if (l15 == 0) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ch = cw + 4 * l4 + e;
         if (ch < hid) {
-          p.stats_part[((size_t)row_id * 2 + 0) * hid + ch] = s1[e];
-          p.stats_part[((size_t)row_id * 2 + 1) * hid + ch] = s2[e];
+          p.stats_part[((size_t)row_id * 2 + 0) * hid + ch] = t1[e];
+          p.stats_part[((size_t)row_id * 2 + 1) * hid + ch] = t2[e];
         }
       }
     }
@@ -286,6 +374,7 @@ struct DwxBwdParams {
   int act1;
   int B, H, W, Ho, Wo, hid;
   int tiles_h, tiles_w, ntiles, chunks;
+  int dbg;      // developer knob (CVH_TUNE key 17)
 };
 
 template <int S, int CIN>
@@ -298,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
   bf16_t* dt = reinterpret_cast<bf16_t*>(smem_raw);   // [ND][DX_AP]  dy of this workgroup's 64 channels (zero outside the image)
   bf16_t* zt = dt + ND * DX_AP;                        // [128][DX_AP] z = act(bn1(y1)) at the own pixels
   bf16_t* xo = zt + 128 * DX_AP;                       // [128][XP]    block input at the own pixels
-  float* cst = reinterpret_cast<float*>(xo + 128 * XP);  // [7][64] ca, cb, cc; mean, invstd, scale, shift
+  float* cst = reinterpret_cast<float*>(xo + 128 * XP);  // [9][64] ca, cb, cc; sc, sh, nsc, nsh, is, nmi
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
@@ -333,13 +422,23 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
     wdf[3] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(3, 0, 0), dx2_tap(3, 0, 1), l15, l4);
     wdf[4] = diag_frag2(p.wd, hid, cw + l15, dx2_tap(3, 1, 0), dx2_tap(3, 1, 1), l15, l4);
   }
-  // mean, invstd, scale, shift of this workgroup's channels: read from LDS where they are used (16 registers otherwise)
-  for (int i = tid; i < 4 * DX_CC; i += 256) {
-    const int v = i / DX_CC, c = c0 + (i - v * DX_CC);
-    cst[3 * DX_CC + i] = c < hid ? p.in_stats[(size_t)v * hid + c] : 0.f;
+  // per-channel constants of the expansion BatchNorm, read from LDS where they are used (24 registers otherwise), in the form the
+  // epilogue consumes: yh = sc y + sh, exponent of the sigmoid exp2(nsc y + nsh), xhat = is y + nmi
+  for (int i = tid; i < DX_CC; i += 256) {
+    const int c = c0 + i;
+    const bool ok = c < hid;
+    const float mu_ = ok ? p.in_stats[c] : 0.f, is_ = ok ? p.in_stats[(size_t)hid + c] : 0.f;
+    const float sc_ = ok ? p.in_stats[(size_t)2 * hid + c] : 0.f, sh_ = ok ? p.in_stats[(size_t)3 * hid + c] : 0.f;
+    float* d = cst + 3 * DX_CC + i;
+    d[0] = sc_;
+    d[DX_CC] = sh_;
+    d[2 * DX_CC] = -1.4426950408889634f * sc_;
+    d[3 * DX_CC] = -1.4426950408889634f * sh_;
+    d[4 * DX_CC] = is_;
+    d[5 * DX_CC] = -mu_ * is_;
   }
   const float* bn1 = cst + 3 * DX_CC + 16 * wave + 4 * l4;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2_t s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
   f32x4_t dwa[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) dwa[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -387,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
     const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
     const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
     const int hi0 = th * TL::OH * S, wi0 = tw * TL::OW * S;
+    bf16_t* gbase = p.g_in + (((size_t)b * p.H + hi0) * p.W + wi0) * hid;  // wave-uniform: the lanes add 32-bit offsets
 
     __syncthreads();  // every wave is done with the previous tile (first iteration: the zero fill and the coefficients are in place)
     {
@@ -418,7 +518,12 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
               v8_unpack(gv, g);
               v8_unpack(yv, y);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) g[j] = ka[j] * g[j] + kb[j] * y[j] + kc[j];
+              for (int j = 0; j < 8; j += 2) {  // v_pk_fma_f32: two channels per instruction
+                const f32x2_t r = f32x2_t{ka[j], ka[j + 1]} * f32x2_t{g[j], g[j + 1]} +
+                                  (f32x2_t{kb[j], kb[j + 1]} * f32x2_t{y[j], y[j + 1]} + f32x2_t{kc[j], kc[j + 1]});
+                g[j] = r[0];
+                g[j + 1] = r[1];
+              }
               v8_pack(g, o);
             } else {
               o = gv;
@@ -493,32 +598,38 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
         }
       }
 
-      float z[4], gp[4], xh[4], mu[4], is[4], sc[4], sh[4];
-      *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(bn1);
-      *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(bn1 + DX_CC);
-      *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(bn1 + 2 * DX_CC);
-      *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(bn1 + 3 * DX_CC);
+      // epilogue on packed pairs (the VALU bounds this kernel: v_pk_* do two channels per 4-cycle slot): SiLU and its derivative from one
+      // sigmoid, xhat, g1 = dz * act'; y1 enters in fp32 exactly as in the forward kernel; statistics from the fp32 values
+      uint32_t zw[2], gw[2];
+      f32x2_t gq[2], xq2[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float y1 = rbf(a1[e]);  // y1 as the forward kernel saw it
-        const float yh = sc[e] * y1 + sh[e];
-        const float sg = sigmoidf_(yh);  // SiLU and its derivative from one sigmoid
-        z[e] = yh * sg;
-        gp[e] = sg * (1.0f + yh * (1.0f - sg));
-        xh[e] = (y1 - mu[e]) * is[e];
+      for (int h = 0; h < 2; ++h) {
+        const f32x2_t cs = *reinterpret_cast<const f32x2_t*>(bn1 + 2 * h), csh = *reinterpret_cast<const f32x2_t*>(bn1 + DX_CC + 2 * h);
+        const f32x2_t cn = *reinterpret_cast<const f32x2_t*>(bn1 + 2 * DX_CC + 2 * h), cnh = *reinterpret_cast<const f32x2_t*>(bn1 + 3 * DX_CC + 2 * h);
+        const f32x2_t ci = *reinterpret_cast<const f32x2_t*>(bn1 + 4 * DX_CC + 2 * h), cm = *reinterpret_cast<const f32x2_t*>(bn1 + 5 * DX_CC + 2 * h);
+        const f32x2_t y = {a1[2 * h], a1[2 * h + 1]};
+        const f32x2_t yh = cs * y + csh;
+        const f32x2_t t = cn * y + cnh;
+        f32x2_t d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        d = d + 1.0f;
+        const f32x2_t sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2_t z = yh * sg;
+        const f32x2_t gp = sg * (yh * (1.0f - sg) + 1.0f);
+        const f32x2_t g = f32x2_t{a2[2 * h], a2[2 * h + 1]} * gp;
+        zw[h] = f2bf_pk(z[0], z[1]);
+        gw[h] = f2bf_pk(g[0], g[1]);
+        gq[h] = g;
+        xq2[h] = ci * y + cm;
       }
-      if (!pok) z[0] = z[1] = z[2] = z[3] = 0.f;
-      *reinterpret_cast<uint2*>(zt + opx * DX_AP + 16 * wave + 4 * l4) = make_uint2(f2bf_pk(z[0], z[1]), f2bf_pk(z[2], z[3]));
-      const int ch = cw + 4 * l4;
-      if (pok && ch < hid) {
-        const uint2 pk = make_uint2(f2bf_pk(a2[0] * gp[0], a2[1] * gp[1]), f2bf_pk(a2[2] * gp[2], a2[3] * gp[3]));
-        *reinterpret_cast<uint2*>(p.g_in + (((size_t)b * p.H + hi) * p.W + wi) * hid + ch) = pk;
-        const float q[4] = {bf2f((uint16_t)(pk.x & 0xffff)), bf2f((uint16_t)(pk.x >> 16)), bf2f((uint16_t)(pk.y & 0xffff)),
-                            bf2f((uint16_t)(pk.y >> 16))};  // statistics of the values as stored
+      const uint32_t zm = pok ? 0xffffffffu : 0u;  // a pixel outside the image contributes nothing to dW
+      *reinterpret_cast<uint2*>(zt + opx * DX_AP + 16 * wave + 4 * l4) = make_uint2(zw[0] & zm, zw[1] & zm);
+      if (pok && cw + 4 * l4 < hid) {
+        const int goff = (int)(__umul24(__umul24(r, p.W) + c, hid)) + cw + 4 * l4;  // elements from the tile's first pixel
+        *reinterpret_cast<uint2*>(gbase + goff) = make_uint2(gw[0], gw[1]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s1[e] += q[e];
-          s2[e] += q[e] * xh[e];
+        for (int h = 0; h < 2; ++h) {
+          s1[h] += gq[h];
+          s2[h] += gq[h] * xq2[h];
         }
       }
     }
@@ -562,20 +673,21 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
   }
 
   // ---- workgroup results: statistics and the diagonal of the dW accumulators ----
+  float t1[4] = {s1[0][0], s1[0][1], s1[1][0], s1[1][1]}, t2[4] = {s2[0][0], s2[0][1], s2[1][0], s2[1][1]};
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) {
-      s1[e] += __shfl_xor(s1[e], m, 64);
-      s2[e] += __shfl_xor(s2[e], m, 64);
+      t1[e] += __shfl_xor(t1[e], m, 64);
+      t2[e] += __shfl_xor(t2[e], m, 64);
     }
   if (l15 == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ch = cw + 4 * l4 + e;
       if (ch < hid) {
-        p.stats_part[((size_t)row_id * 2 + 0) * hid + ch] = s1[e];
-        p.stats_part[((size_t)row_id * 2 + 1) * hid + ch] = s2[e];
+        p.stats_part[((size_t)row_id * 2 + 0) * hid + ch] = t1[e];
+        p.stats_part[((size_t)row_id * 2 + 1) * hid + ch] = t2[e];
       }
     }
   }
@@ -624,11 +736,11 @@ __global__ __launch_bounds__(128) void gram_bn_stats_kernel(const float* __restr
 template <int S, int CIN> size_t dwx_fwd_smem() {
   using TL = DxTile<S>;
   constexpr int NPB = (TL::IH * TL::IW + 15) / 16;
-  return (size_t)NPB * 16 * (32 * ((CIN + 31) / 32) + 8 + DX_AP) * 2;
+  return (size_t)NPB * 16 * (dx_xp<CIN>() + DX_CC) * 2;
 }
 
 template <int S, int CIN> size_t dwx_bwd_smem() {
-  return ((size_t)(DxBwd<S>::DH * DxBwd<S>::DW + 128) * DX_AP + (size_t)128 * (32 * ((CIN + 31) / 32) + 8)) * 2 + 7 * DX_CC * 4;
+  return ((size_t)(DxBwd<S>::DH * DxBwd<S>::DW + 128) * DX_AP + (size_t)128 * (32 * ((CIN + 31) / 32) + 8)) * 2 + 9 * DX_CC * 4;
 }
 
 bool dwx_cin_ok(int Cin) { return Cin == 16 || Cin == 32 || Cin == 64 || Cin == 96 || Cin == 128; }
@@ -639,8 +751,8 @@ int dwx_plan(int B, int Ho, int Wo, int hid, int stride, int* tiles_h, int* tile
   *tiles_w = (Wo + OW - 1) / OW;
   *chunks = (hid + DX_CC - 1) / DX_CC;
   const long long ntiles = (long long)B * *tiles_h * *tiles_w;
-  int rows = 2048 / *chunks;  // ~2048 workgroups in XCD-contiguous round-robin order; partial-statistics rows <= 512
-  if (rows > 512) rows = 512;
+  int rows = 2048 / *chunks;  // ~2048 workgroups in XCD-contiguous round-robin order (up to 4 resident per CU); partial rows <= 1024
+  if (rows > 1024) rows = 1024;
   if (rows < 32) rows = 32;
   if (rows > ntiles) rows = (int)ntiles;
   return rows;
@@ -676,6 +788,7 @@ extern "C" int cvh_dwx_fwd(int dtype, const void* x, const void* w1, const float
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.hid = hid;
   const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
   p.ntiles = B * p.tiles_h * p.tiles_w;
+  p.dbg = cvh_tune_get(17);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
   int dev = 0;
@@ -727,6 +840,7 @@ extern "C" int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.hid = hid;
   const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
   p.ntiles = B * p.tiles_h * p.tiles_w;
+  p.dbg = cvh_tune_get(17);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
   int dev = 0;

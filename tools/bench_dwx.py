@@ -32,10 +32,17 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="both")
+    ap.add_argument("--dbg", type=int, default=0, help="CVH_TUNE key 17: phase-skip bits of the dwx kernels (timing experiments; results wrong)")
+    ap.add_argument("--shape", type=int, default=-1, help="index into SHAPES (-1: all)")
+    ap.add_argument("--narrow", type=int, default=0, help="CVH_TUNE key 19 = 1: 8-byte stores straight from the accumulators")
+    ap.add_argument("--stagger", type=int, default=0, help="CVH_TUNE key 18: start-up de-phasing of the dwx workgroups (x ~1k cycles)")
     a = ap.parse_args()
     B = a.batch
     st = torch.cuda.current_stream().cuda_stream
-    for (H, W, Cin, hid, s) in SHAPES:
+    _lib.call("cvh_set_tuning", 17, a.dbg)
+    _lib.call("cvh_set_tuning", 18, a.stagger)
+    _lib.call("cvh_set_tuning", 19, a.narrow)
+    for (H, W, Cin, hid, s) in (SHAPES if a.shape < 0 else [SHAPES[a.shape]]):
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         g = torch.Generator(device=DEV).manual_seed(1)
         x = torch.randn(B, H, W, Cin, device=DEV, generator=g).bfloat16()

@@ -271,11 +271,14 @@ def run(args):
     # gradients live in flat fp32 buckets (one zero-fill per step, one RCCL message per bucket); with world == 1 the wrapper
     # only provides the flat storage.  Backward kernels add parameter gradients straight into those buffers.
     # (buckets: 1 MB first, 8 MB after — MobileViT-S = 4 messages; cvnets_amd/ddp.py)
-    ddp = DistributedDataParallel(model, broadcast_buffers=False)
-    # autograd hooks do not run on a hipGraph REPLAY, but they do run while the step is CAPTURED: the capture below enables them, so the
-    # side-stream fork behind the last gradient kernel of every bucket and the join at the end of backward become graph edges and the
-    # replayed step overlaps the all-reduces with the rest of backward.  Eager steps (warm-up, --no-graph) reduce after backward.
+    # In-place parameter gradients never reach autograd, so per-parameter hooks cannot drive the exchange; the wrapper's BOUNDARY hooks do:
+    # when backward passes the input of the earliest top-level child of a bucket, the bucket's all-reduce forks onto the side stream.  Python
+    # hooks do not run on a hipGraph REPLAY, but they do run while the step is CAPTURED: the capture below enables them, so the forks behind
+    # the last gradient kernel of every bucket and the join at the end of backward become graph edges and the replayed step overlaps the
+    # all-reduces with the rest of backward.  Eager steps (warm-up, --no-graph) reduce after backward.
+    ddp = DistributedDataParallel(model, broadcast_buffers=False, boundary_overlap=True)
     ddp.hooks_enabled = False
+    ddp.boundary_enabled = False
     cvnets_amd.ops.set_inplace_param_grads(True)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = None
@@ -362,14 +365,14 @@ def run(args):
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls belong to the graph
-                early0 = ddp.early_launches
+                early0, fin0 = ddp.early_launches, ddp.finish_count
                 with torch.cuda.graph(g, stream=cap_stream, capture_error_mode="thread_local"):
                     ddp.zero_grad()
-                    ddp.hooks_enabled = bool(in_graph) and os.environ.get("CVH_GRAPH_OVERLAP", "1") != "0"
-                    static_loss = fwd_bwd()  # hooks on: every complete bucket forks onto the side stream; `finish` joins at the end of backward
-                    if in_graph and not ddp.hooks_enabled:
+                    ddp.boundary_enabled = bool(in_graph) and os.environ.get("CVH_GRAPH_OVERLAP", "1") != "0"
+                    static_loss = fwd_bwd()  # boundaries on: every complete bucket forks onto the side stream; `finish` joins at the end of backward
+                    ddp.boundary_enabled = False
+                    if in_graph and ddp.finish_count == fin0:  # no boundary fired (switched off / unsupported model): one exchange after backward
                         ddp.allreduce_flat()
-                    ddp.hooks_enabled = False
                     if opt is not None and (not multi or in_graph):
                         opt_step()
                 graph, graph_has_allreduce, graph_err = g, in_graph, None
@@ -378,7 +381,7 @@ def run(args):
             except Exception as e:  # pragma: no cover - reported in the JSON line
                 graph_err = f"{type(e).__name__}: {e}"[:300]
                 graph = None
-                ddp.hooks_enabled = False
+                ddp.boundary_enabled = False
                 torch.cuda.synchronize()
 
     for _ in range(args.warmup):

@@ -83,7 +83,8 @@ class _Bucket:
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, bucket_cap_mb: float = 8.0, overlap: bool = True, broadcast_buffers: bool = True,
-                 process_group=None, force_collectives: Optional[bool] = None, first_bucket_mb: float = 1.0):
+                 process_group=None, force_collectives: Optional[bool] = None, first_bucket_mb: float = 1.0,
+                 boundary_overlap: bool = False):
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -140,9 +141,81 @@ class DistributedDataParallel(nn.Module):
         self.early_launches = 0   # buckets whose all-reduce started from a hook, i.e. before the end of backward (overlapped)
         self.late_launches = 0    # buckets that `finish` / `allreduce_flat` had to launch (no overlap: e.g. a parameter without gradient)
         self._warned_no_overlap = False
+        self.finish_count = 0     # completed end-of-backward exchanges (hook- or boundary-driven)
+        # Overlap WITHOUT per-parameter hooks (`boundary_overlap`): with in-place parameter gradients (ops.set_inplace_param_grads — the kernels add
+        # straight into the bucket views, autograd never sees those gradients and post-accumulate hooks do not fire) a bucket is known to be
+        # complete when backward has passed the INPUT of the earliest top-level child that owns one of its parameters: a tensor hook on that
+        # input (attached by a forward pre-hook) flushes the deferred dW reductions queued so far and starts the bucket's all-reduce on the side
+        # stream.  Requires the top-level children to run in registration order, each consuming the previous one's output (MobileViT /
+        # MobileViTv2: conv_1, layer_1..5, conv_1x1_exp, classifier) and no parameter shared across children; the order is verified on every
+        # forward and the feature switches itself off (with a warning) if it does not hold.  Works inside a hipGraph capture: the forks and
+        # the join at `finish` become graph edges (bench.py).
+        self.boundary_overlap = False
+        self._boundary_buckets = {}
+        self._boundary_seen = -1
+        if boundary_overlap:
+            self._setup_boundaries()
         self._buf_span = None
         if self.flat_buffers is not None and fbufs:
             self._buf_span = tuple(fbufs)  # every re-pointed buffer is checked before the flat broadcast (a partial .float() / re-registration)
+
+    # ---- boundary-driven overlap (in-place parameter gradients / captured steps) ----------------
+    def _setup_boundaries(self):
+        children = list(self.module.children())
+        owner = {}
+        for ci, ch in enumerate(children):
+            for p in ch.parameters():
+                if p in owner:  # a parameter shared between top-level children: its gradient is complete only at the earlier one
+                    return
+                owner[p] = ci
+        if any(p not in owner for b in self.buckets for p in b.params):
+            return  # parameters registered directly on the root module
+        for b in self.buckets:
+            ci = min(owner[p] for p in b.params)
+            self._boundary_buckets.setdefault(ci, []).append(b)
+        for ci, ch in enumerate(children):
+            ch.register_forward_pre_hook(lambda mod, args, ci=ci: self._pre_forward(ci, args))
+        self.boundary_overlap = True
+
+    def _pre_forward(self, ci: int, args):
+        if not self.boundary_overlap:
+            return None
+        if ci == 0:
+            self._boundary_seen = 0
+        elif ci < self._boundary_seen:
+            import warnings
+            warnings.warn("cvnets_amd.ddp: top-level children do not run in registration order: boundary overlap disabled")
+            self.boundary_overlap = False
+            return None
+        else:
+            self._boundary_seen = ci
+        if ci in self._boundary_buckets and self.active and self.boundary_enabled and torch.is_grad_enabled() and args \
+                and isinstance(args[0], torch.Tensor) and args[0].requires_grad:
+            args[0].register_hook(lambda g, ci=ci: self._boundary(ci))
+        return None
+
+    boundary_enabled = True
+
+    def _boundary(self, ci: int):
+        """backward has produced the gradient w.r.t. the input of child `ci`: every parameter of children >= ci has its gradient kernels
+        (or deferred partial sums) enqueued"""
+        if not (self.active and self.boundary_overlap and self.boundary_enabled):
+            return None
+        tid = torch._C._current_graph_task_id()
+        if self._callback_task != tid:
+            if self._callback_task is not None:
+                for b in self.buckets:
+                    b.work = None
+                    b.pending = len(b.params)
+            self._callback_task = tid
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        from . import ops
+        ops.flush_deferred_reductions()  # the partial sums queued so far all belong to children >= ci
+        for b in self._boundary_buckets[ci]:
+            if b.work is None:
+                self.early_launches += 1
+                self._launch(b)
+        return None
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -192,6 +265,9 @@ class DistributedDataParallel(nn.Module):
 
     def finish(self):
         """end of backward: launch whatever was not launched, wait, average."""
+        from . import ops
+        ops.flush_deferred_reductions()  # whichever end-of-backward callback runs first: no partial sum may still be queued
+        self.finish_count += 1
         late = 0
         for b in self.buckets:
             if b.work is None:
@@ -231,8 +307,9 @@ class DistributedDataParallel(nn.Module):
         new.use_side_stream, new.side_stream, new.flat_buffers, new._buf_span = False, None, None, None
         new._avg_op, new.buckets, new._bucket_of = None, [], {}
         new._callback_task, new.hooks_enabled = None, False
-        new.early_launches = new.late_launches = 0
+        new.early_launches = new.late_launches = new.finish_count = 0
         new._warned_no_overlap = True
+        new.boundary_overlap, new._boundary_buckets, new._boundary_seen = False, {}, -1
         new.training = self.training
         return new
 

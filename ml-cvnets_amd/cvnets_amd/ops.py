@@ -476,6 +476,12 @@ def defer_reduce(part, out, rows, row_stride, n_out, *, kind=0, N=0, Ktot=0, Cin
     return True
 
 
+def flush_deferred_reductions() -> None:
+    """launch the reductions queued so far NOW (cvnets_amd.ddp: a gradient bucket is about to be all-reduced inside backward); later
+    reductions of the same backward queue up again and are flushed by the end-of-backward callback"""
+    _flush_deferred_reductions()
+
+
 def _flush_deferred_reductions() -> None:
     if not _pending_reductions:
         return

@@ -99,3 +99,33 @@ def test_dw_kernel_emits_bias_gradient_through_ones_column(M, N, K):
     assert torch.allclose(bpart.double().sum(0), want_b, rtol=1e-5, atol=1e-4 * float(want_b.abs().max()))
     want_w = dy.float().double().t() @ x.float().double()
     assert float((dw.double() - want_w).norm() / want_w.norm()) < 1e-5
+
+
+def test_channels_last_model_with_contiguous_input_takes_a_correct_stem_path():
+    """launch.py moves the model to channels_last when `common.channels_last` is set; conv_1.weight then has strides
+    (27, 1, 9, 3) and the stem kernels (which read dense OIHW) must not be chosen for it.  Same logits / stem gradient as the contiguous model."""
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+    from oracle.weights import seeded_input, seeded_labels, seeded_state_dict
+    opts = default_opts(**{"model.classification.mit.mode": "xx_small", "model.classification.mit.dropout": 0.0,
+                           "model.classification.classifier_dropout": 0.0})
+    outs = []
+    x, y = seeded_input((4, 3, 64, 64), seed=3).cuda(), seeded_labels(4, 1000, seed=3).cuda()
+    cvnets_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        for cl in (False, True):
+            m = cvnets_amd.MobileViT(opts)
+            m.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0))
+            m = m.cuda().train()
+            if cl:
+                m = m.to(memory_format=torch.channels_last)
+                assert not m.conv_1.block.conv.weight.is_contiguous()
+            logits = m(x)
+            torch.nn.functional.cross_entropy(logits.float(), y).backward()
+            torch.cuda.synchronize()
+            outs.append((logits.detach().float(), m.conv_1.block.conv.weight.grad.detach().float().contiguous()))
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    (l0, g0), (l1, g1) = outs
+    assert float((l0 - l1).norm() / l0.norm()) < 5e-2  # two bf16 realisations of the same network (different stem kernels)
+    assert float((g0 - g1).norm() / g0.norm()) < 2.5e-1

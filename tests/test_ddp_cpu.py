@@ -29,8 +29,13 @@ def _worker(rank, world, port, explicit, q):
     assert distributed_init("gloo", torch.device("cpu")) == rank
     torch.manual_seed(100 + rank)  # different init per rank: the ctor broadcast must fix that
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
-    ddp = DistributedDataParallel(net, bucket_cap_mb=0.001, overlap=True)  # tiny cap -> several buckets
+    boundary = explicit == "boundary"
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001, first_bucket_mb=0.0001, overlap=True, boundary_overlap=boundary)  # tiny cap -> several buckets
     assert len(ddp.buckets) >= 3
+    if boundary:  # no per-parameter hooks (the in-place-gradient regime of bench.py): the exchange is driven by the child-input boundaries
+        assert ddp.boundary_overlap
+        ddp.hooks_enabled = False
+        explicit = False
     w0 = [p.detach().clone() for p in net.parameters()]
     gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
     dist.all_gather(gathered, w0[0])
@@ -59,9 +64,12 @@ def _worker(rank, world, port, explicit, q):
         for a, p2 in zip(ref, net2.parameters()):
             a += p2.grad / world
     err = max(float((a - b).abs().max()) for a, b in zip(got, ref))
+    if boundary:  # buckets of the later children started inside backward; the first child's (its input needs no gradient) at the end
+        rep = ddp.overlap_report()
+        assert rep["launched_during_backward"] >= 2 and rep["launched_at_end_of_backward"] >= 1, rep
     # a second step must work too (bucket counters reset)
     ddp.zero_grad()
-    ddp.hooks_enabled = not explicit
+    ddp.hooks_enabled = not explicit and not boundary
     ddp(x).square().mean().backward()
     if explicit:
         ddp.allreduce_flat()
@@ -69,7 +77,7 @@ def _worker(rank, world, port, explicit, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("explicit", [False, True])
+@pytest.mark.parametrize("explicit", [False, True, "boundary"])
 def test_ddp_gloo_world2(explicit):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -175,3 +183,23 @@ def test_ddp_set_to_none_gradients_are_readopted():
         assert p.exitcode == 0
     for rank, ok in sorted(q.get(timeout=5) for _ in range(2)):
         assert ok, rank
+
+
+def test_ddp_wrapper_can_be_copied_and_pickled():
+    """EMA deep-copies the WRAPPED model (cvnets/misc/averaging_utils.py:33) and torch.save pickles it: the copy is a passive holder of a copy
+    of `.module` (no stream, no process group, no buckets, no hooks) with the same state_dict keys."""
+    import copy
+    import pickle
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    from cvnets_amd.ddp import DistributedDataParallel
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+    ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001)
+    import threading
+    ddp.side_stream = threading.Lock()  # stands in for the HIP stream the GPU wrapper holds: neither copyable nor picklable
+    for c in (copy.deepcopy(ddp), pickle.loads(pickle.dumps(ddp))):
+        assert isinstance(c, DistributedDataParallel) and not c.active and c.side_stream is None and not c.buckets
+        assert list(c.state_dict().keys()) == list(ddp.state_dict().keys()) and c.module is not ddp.module
+        c.eval()
+        assert c(torch.randn(4, 16)).shape == (4, 8)
+        for a, b in zip(c.parameters(), ddp.parameters()):  # the reference's EMA update (averaging_utils.py:43-55)
+            a.detach().mul_(0.5).add_(b.detach(), alpha=0.5)

@@ -103,7 +103,7 @@ def test_eager_hooks_side_stream_allreduce_avg(rccl_world1, monkeypatch):
         cvnets_amd.set_compute_dtype(None)
 
 
-@pytest.mark.parametrize("in_graph", [False, True])
+@pytest.mark.parametrize("in_graph", [False, True, "overlap"])
 def test_captured_step_with_rccl_allreduce(rccl_world1, in_graph):
     """bench.py's N > 1 path: hipGraph capture (capture_error_mode="thread_local", the RCCL watchdog thread is alive) of zero-grad + forward
     + loss + backward with in-place bucket gradients [+ the bucket all-reduces and the fused AdamW as graph nodes], replayed; against
@@ -115,10 +115,16 @@ def test_captured_step_with_rccl_allreduce(rccl_world1, in_graph):
     cvnets_amd.set_compute_dtype(torch.float32)
     ops.set_inplace_param_grads(True)
     try:
+        overlap = in_graph == "overlap"
+
         def make():
             m = _model()
-            ddp = DistributedDataParallel(m, bucket_cap_mb=1.0, broadcast_buffers=False, force_collectives=True)
+            # "overlap": bench.py's N > 1 configuration — the buckets fork onto the side stream INSIDE the captured backward, driven by the
+            # child-input boundaries (in-place gradients never reach autograd hooks); xx_small = 5.1 MB -> 4 buckets of >= 0.25 / 1 MB
+            ddp = DistributedDataParallel(m, bucket_cap_mb=1.0, first_bucket_mb=0.25, broadcast_buffers=False, force_collectives=True,
+                                          boundary_overlap=overlap)
             ddp.hooks_enabled = False
+            ddp.boundary_enabled = False
             opt = cvnets_amd.optim.AdamW(list(m.parameters()), lr=1e-3, weight_decay=0.01)
             return m, ddp, opt
 
@@ -147,11 +153,20 @@ def test_captured_step_with_rccl_allreduce(rccl_world1, in_graph):
         torch.cuda.synchronize()
         assert abs(float(l0) - ref_losses[0]) < 1e-5
         g = torch.cuda.CUDAGraph()
+        early0, fin0 = ddp.early_launches, ddp.finish_count
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             ddp.zero_grad()
+            ddp.boundary_enabled = overlap
             static_loss = ops.cross_entropy(m(x), y, 0.1)
             static_loss.backward()
-            if in_graph:
+            ddp.boundary_enabled = False
+            if overlap:
+                # at least two all-reduce nodes were forked before the last backward kernel was captured; `finish` joined them and
+                # launched the first child's bucket at the end of backward
+                assert ddp.boundary_overlap and ddp.finish_count == fin0 + 1, (ddp.boundary_overlap, ddp.finish_count)
+                assert ddp.early_launches - early0 >= 2, ddp.overlap_report()
+                opt.step(sync_hyperparameters=False)
+            elif in_graph:
                 ddp.allreduce_flat()
                 opt.step(sync_hyperparameters=False)
         losses = []
@@ -209,3 +224,30 @@ def test_gather_all_features_allgather_reducescatter(rccl_world1):
         res.append((loss.detach(), a.grad.clone(), b.grad.clone()))
     assert torch.allclose(res[0][0], res[1][0], rtol=1e-6)
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-7) and torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-7)
+
+
+def test_wrapper_deepcopy_and_ema_update_on_gpu(rccl_world1):
+    """the reference's EMA deep-copies the DDP-wrapped model (cvnets/misc/averaging_utils.py:33); the GPU wrapper holds
+    a HIP stream, which cannot be copied — the copy must be a passive holder of a copy of the module, and the EMA update must run."""
+    import copy
+    from cvnets_amd.ddp import DistributedDataParallel
+    m = _model()
+    ddp = DistributedDataParallel(m, broadcast_buffers=False, force_collectives=True)
+    assert ddp.side_stream is not None
+    ema = copy.deepcopy(ddp)
+    ema.eval()
+    assert not ema.active and ema.side_stream is None and hasattr(ema, "module")
+    msd = ddp.state_dict()
+    with torch.no_grad():
+        for k, v in ema.state_dict().items():  # averaging_utils.py:43-55
+            if v.is_floating_point():
+                v.copy_(v * (1.0 - 0.0005) + 0.0005 * msd[k].detach())
+    x, _ = _batch()
+    import cvnets_amd
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        with torch.no_grad():
+            out = ema(x)
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    assert out.shape == (4, 1000) and torch.isfinite(out).all()

@@ -82,7 +82,7 @@ template <int CIN> __host__ __device__ constexpr int dx_xp() { return 32 * ((CIN
 #define DX_OCC16 3
 #endif
 #ifndef DX_OCC64
-#define DX_OCC64 3
+#define DX_OCC64 2
 #endif
 template <int CIN> __host__ __device__ constexpr int dx_fwd_occ() { return CIN <= 16 ? DX_OCC16 : (CIN <= 32 ? 3 : (CIN <= 64 ? DX_OCC64 : 2)); }
 
@@ -150,10 +150,29 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
   const int t_step = gridDim.x / p.chunks;
   uint4 xr[NXL];
   uint32_t xok = 0;
+  // tile-independent part of the load addressing (elements from the tile's first halo pixel), so that an interior tile — all of its
+  // halo inside the image: a wave-uniform test — costs one add per load instead of the div / mod / compare / 64-bit multiply chain
+  int xoff[NXL];
+  uint32_t xin = 0;
+#pragma unroll
+  for (int it = 0; it < NXL; ++it) {
+    const int i = tid + it * 256;
+    const int px = i / XC, ck = i - px * XC;
+    const int pr = px / TL::IW, pc = px - pr * TL::IW;
+    xoff[it] = (pr * p.W + pc) * CIN + ck * 8;
+    xin |= (i < NPIX * XC ? 1u : 0u) << it;
+  }
   auto load_x = [&](int tix) __attribute__((always_inline)) {
     const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
     const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
     const int hi0 = th * TL::OH * S - 1, wi0 = tw * TL::OW * S - 1;
+    if (hi0 >= 0 && wi0 >= 0 && hi0 + TL::IH <= p.H && wi0 + TL::IW <= p.W) {
+      const bf16_t* base = p.x + (((size_t)b * p.H + hi0) * p.W + wi0) * CIN;
+      xok = xin;
+#pragma unroll
+      for (int it = 0; it < NXL; ++it) xr[it] = *reinterpret_cast<const uint4*>(((xin >> it) & 1u) ? base + xoff[it] : p.x);
+      return;
+    }
     xok = 0;
 #pragma unroll
     for (int it = 0; it < NXL; ++it) {

@@ -186,6 +186,154 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves — the MFMA-bound transformer linears (ViT-B / CLIP: N, K = 512 ... 3072).
+// What bounds these GEMMs on this chip is the L2 -> LDS path of a CU, not the matrix pipe: measured with the direct-to-LDS loads of the
+// kernels in this file it sustains ~10 B/clk/CU with 64-byte row segments and roughly twice that with 128-byte ones, against the 62 B/clk/CU
+// the 128 x 128 kernel above would need at the matrix pipe's full rate (two workgroups x 32 KB per 128 MFMAs) — it tops out at 600-800
+// TFLOP/s.  Here a workgroup owns 256 x 256 outputs (each wave 64 x 128 = 2 x 4 MFMA 32x32x16 accumulators, 128 registers): 64 KB per
+// 256 MFMAs of a CU, half the bytes per flop, in the same 128-byte rows / XOR swizzle as above; two 64 KB stage buffers (a K step = 64
+// is 2048 matrix-pipe cycles per SIMD: longer than the load latency, so one step of loads in flight is enough).  One barrier per K step;
+// XCD-contiguous tile order with the N tile fastest.  (A first version with 32-wide K steps in four buffers — three steps of loads in
+// flight — measured the same 600 TFLOP/s as the 128 x 128 kernel: its 64-byte row segments halve what the path delivers.)
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int B2_TILE = 256 * BK * 2;      // 32 KB per operand tile
+constexpr int B2_STAGE = 2 * B2_TILE;      // A | B
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (A tile | B tile); reused by the epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // 4 x 2 waves: rows 64 wr .., columns 128 wc ..
+  const int K = p.Ktot, N = p.N, M = p.M;
+  const int NT = N / 256;
+  const int total = p.m_tiles * NT;
+  const int L = xcd_chunk_id(blockIdx.x, total);
+  const int mt = L / NT, nt = L - mt * NT;
+  const int m0 = mt * 256, n0 = nt * 256;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.src1);
+  const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(p.wgt);
+
+  // direct-to-LDS assignment: wave-instruction i (32 per operand and stage) covers tile rows [8 i, 8 i + 8); lane -> (row, LDS slot);
+  // wave w issues instructions 4w .. 4w + 3 of A and of B
+  const bf16_t* ga[4];
+  const bf16_t* gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (4 * wave + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);  // global chunk that belongs in LDS slot (lane & 7) of this row
+    int am = m0 + row;
+    if (am > M - 1) am = M - 1;  // rows past M: read a valid row, the result is never stored
+    ga[j] = A + (size_t)am * K + c * 8;
+    gb[j] = Wp + (size_t)(n0 + row) * K + c * 8;
+  }
+  auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    unsigned char* dst = smem + buf * B2_STAGE + (4 * wave) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(ga[j] + kt * BK, dst + j * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(gb[j] + kt * BK, dst + B2_TILE + j * 1024);
+  };
+
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero();
+
+  const int KT = K / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+    const unsigned char* At = smem + buf * B2_STAGE;
+    const unsigned char* Bt = At + B2_TILE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int chunk = 2 * kk + (lane >> 5);
+      Frag<bf16_t> a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = frag_swz(At, wr * 64 + 32 * i + (lane & 31), chunk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = frag_swz(Bt, wc * 128 + 32 * j + (lane & 31), chunk);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma32(acc[i][j], a[i], b[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // (a) everyone is done reading `buf`, (b) tile kt+1 has landed in buf^1 for all waves
+  }
+
+  // ---- epilogue (semantics of conv_gemm's: bias -> save_pre -> activation -> act-grad -> dropout -> residual), per wave, two halves of
+  //      64 rows x 64 columns through a per-wave LDS staging area so that every store is a full 128-byte row segment ----
+  bf16_t* stg = reinterpret_cast<bf16_t*>(smem) + wave * (64 * STG_PITCH);
+  DropKey dkey = {0u, 0u};
+  if (p.drop_p > 0.f) dkey = drop_key(*p.seed, p.stream_id, p.drop_p);
+  const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
+  const bf16_t* agp = reinterpret_cast<const bf16_t*>(p.actgrad_aux);
+  const bf16_t* rsp = reinterpret_cast<const bf16_t*>(p.residual);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int nw = n0 + wc * 128 + h * 64;  // first column of this half
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int n = nw + tj * 32 + (lane & 31);
+      const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg[(ti * 32 + acc_row(r, lane)) * STG_PITCH + tj * 32 + (lane & 31)] = from_f<bf16_t>(acc[ti][2 * h + tj][r] + bias);
+    }
+    wave_lds_sync();
+    const int ch = lane & 7;
+    const int ncol = nw + ch * 8;
+    V8<bf16_t> agr[8], rsr[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int m = m0 + wr * 64 + pass * 8 + (lane >> 3);
+      const bool ok = m < M;
+      const size_t o = (size_t)m * N + ncol;
+      agr[pass] = v8_load_clamped<bf16_t>(agp ? agp : out, o, ok && agp != nullptr);
+      rsr[pass] = v8_load_clamped<bf16_t>(rsp ? rsp : out, o, ok && rsp != nullptr);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 8 + (lane >> 3);
+      const int m = m0 + wr * 64 + row;
+      if (m < M) {
+        const size_t o = (size_t)m * N + ncol;
+        V8<bf16_t> pv = v8_load<bf16_t>(stg + row * STG_PITCH + ch * 8);
+        if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
+        float v[8];
+        v8_unpack(pv, v);
+        if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
+        if (p.actgrad_aux) {
+          float a[8];
+          v8_unpack(agr[pass], a);
+          act_grad8_mul(v, a, p.actgrad_act);
+        }
+        if (p.drop_p > 0.f) dropout_scale8(dkey, o, inv_keep, v);
+        if (p.residual) {
+          float rr[8];
+          v8_unpack(rsr[pass], rr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+        V8<bf16_t> ov;
+        v8_pack(v, ov);
+        v8_store<bf16_t>(out + o, ov);
+      }
+    }
+    wave_lds_sync();  // the second half reuses the staging area
+  }
+}
+
 bool gemm_big_eligible(const ConvGemmParams& p) {
   if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
   const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
@@ -203,7 +351,21 @@ int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
   ConvGemmParams p = p0;
   const bool ragged = (p.N % BN) != 0 || (p.Ktot % BK) != 0;
   const int n_tiles = (p.N + BN - 1) / BN;
-  if (!ragged && cvh_tune_get(CVH_TUNE_BIG_GEMM) == 2 && p.M >= 8192) {  // 256 x 128 tiles, one 8-wave workgroup per CU
+  if (!ragged && cvh_tune_get(CVH_TUNE_BIG_GEMM) == 1 && (p.N % 256) == 0 && (p.Ktot % BK) == 0 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 1024) {
+    // 256 x 256 tiles, one 8-wave workgroup per CU, at least four rounds of tiles over the 256 CUs (with fewer the tail round costs more than
+    // the larger tile saves: CLIP's text tower at 19.7 k rows stays on the 128 x 128 kernel); knob 3: always the 128 x 128 kernel
+    p.m_tiles = (p.M + 255) / 256;
+    constexpr int smem = 2 * B2_STAGE;  // 128 KB
+    static unsigned attr_done = 0;  // one bit per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done >> (dev & 31)) & 1u)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return (int)e;
+      attr_done |= 1u << (dev & 31);
+    }
+    hipLaunchKernelGGL(gemm_nt256_kernel, dim3(p.m_tiles * (p.N / 256)), dim3(512), smem, st, p);
+  } else if (!ragged && cvh_tune_get(CVH_TUNE_BIG_GEMM) == 2 && p.M >= 8192) {  // 256 x 128 tiles, one 8-wave workgroup per CU
     p.m_tiles = (p.M + 255) / 256;
     constexpr int smem = 2 * (256 + 128) * BK * 2;  // 96 KB
     static bool attr_set = false;

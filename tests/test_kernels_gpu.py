@@ -63,7 +63,9 @@ def test_gemm_asymmetric(ops, dtype):
 LINEAR_SHAPES = [(128, 16, 64), (1000, 64, 32), (257, 144, 432), (4096, 288, 144), (64, 640, 1000), (513, 240, 720), (300, 96, 96),
                  (77, 32, 128), (20000, 32, 128), (130, 384, 192),
                  # transformer-sized linears: bf16 takes the 128x128 direct-to-LDS kernel (csrc/gemm_big.hip) for fwd AND dX
-                 (2500, 768, 768), (2048, 256, 1024), (4100, 3072, 768), (3000, 512, 2304)]
+                 (2500, 768, 768), (2048, 256, 1024), (4100, 3072, 768), (3000, 512, 2304),
+                 # M >= 8192, N % 256 == 0: the 256 x 256 four-stage kernel (gemm_nt256_kernel), rows not a multiple of the tile
+                 (33000, 768, 3072), (87000, 3072, 768), (40000, 512, 2048), (131072 + 5, 64, 512)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -360,13 +362,13 @@ def test_big_gemm_matches_generic_kernel(ops):
     per 64-wide K step is NOT guaranteed, so: tight tolerance, not bit equality), including the dropout mask (same element indexing)."""
     from cvnets_amd import _lib
 
-    M, K, N = 8500, 768, 1536  # M >= 8192 so that knob 2 selects the 256 x 128 tile; M % 256 != 0 exercises the row clamp
+    M, K, N = 44100, 768, 1536  # >= 1024 tiles of 256 x 256 (knob 1 -> gemm_nt256_kernel), M >= 8192 (knob 2 -> 256 x 128); M % 256 != 0: row clamp
     x = _rand(M, K, seed=11).to(torch.bfloat16)
     w = _rand(N, K, seed=12, scale=1 / math.sqrt(K))
     b = _rand(N, seed=13, scale=0.1)
     res = _rand(M, N, seed=14).to(torch.bfloat16)
     outs = []
-    for knob in (1, 0, 2):
+    for knob in (1, 0, 2, 3):  # 1: 256 x 256 four-stage kernel (default for these shapes), 0: generic, 2: 256 x 128, 3: 128 x 128
         _lib.call("cvh_set_tuning", 5, knob)
         try:
             y = ops.LinearAct.apply(x, w, b, res, None, (2, 0.1, 77, False, 0))

@@ -22,6 +22,9 @@ def main():
     t0 = int(step[0]["Start_Timestamp"])
     streams = {}
     print(f"{len(step)} launches, window {(int(step[-1]['End_Timestamp']) - t0) / 1e6:.2f} ms")
+    # rocprofv3's VGPR_Count / Accum_VGPR_Count columns are HALF the per-lane allocation the compiler reports (`.vgpr_count` of the code
+    # object rounded up to the 8-register granule: dwf_bwd_kernel 244 -> 248 -> trace 124; gemm_nt256_kernel 189 -> 192 -> trace 96); the
+    # columns below are the trace values x 2 = allocated registers per lane, the number occupancy follows from (512 / alloc waves per SIMD)
     print(f"{'#':>4s} {'start ms':>9s} {'us':>8s} {'grid':>12s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>7s} {'scr':>4s} q kernel")
     for i, r in enumerate(step):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -29,7 +32,8 @@ def main():
         gx = int(r.get("Grid_Size_X", 0) or 0) // wg
         gy = r.get("Grid_Size_Y", "1")
         q = streams.setdefault(r.get("Queue_Id", r.get("Stream_Id", "0")), len(streams))
-        print(f"{i:4d} {(s - t0) / 1e6:9.3f} {(e - s) / 1e3:8.1f} {f'{gx}x{gy}':>12s} {r.get('VGPR_Count', ''):>5s} {r.get('Accum_VGPR_Count', ''):>5s} "
+        vg, ag = (str(2 * int(r[k])) if (r.get(k) or "").isdigit() else "" for k in ("VGPR_Count", "Accum_VGPR_Count"))
+        print(f"{i:4d} {(s - t0) / 1e6:9.3f} {(e - s) / 1e3:8.1f} {f'{gx}x{gy}':>12s} {vg:>5s} {ag:>5s} "
               f"{r.get('SGPR_Count', ''):>5s} {r.get('LDS_Block_Size', ''):>7s} {r.get('Scratch_Size', ''):>4s} {q} {short(r['Kernel_Name'])}")
 
 

@@ -752,6 +752,13 @@ __global__ __launch_bounds__(128) void gram_bn_stats_kernel(const float* __restr
   }
 }
 
+// out[i] = alpha * a[i] + (b ? b[i] : 0): column sums of an InvertedResidual output without a pass over it — the block ends in a train-mode
+// BatchNorm, so sum_rows bn3(y3)[c] = rows * beta3[c] exactly (+ the column sums of the input on the residual path)
+__global__ void axpb_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = alpha * a[i] + (b != nullptr ? b[i] : 0.f);
+}
+
 template <int S, int CIN> size_t dwx_fwd_smem() {
   using TL = DxTile<S>;
   constexpr int NPB = (TL::IH * TL::IW + 15) / 16;
@@ -790,6 +797,13 @@ extern "C" int cvh_gram_bn_stats(const float* G, const float* s, const void* w1,
   if (K <= 0 || K > 128 || hid <= 0) return -2;
   hipLaunchKernelGGL(gram_bn_stats_kernel, dim3(hid), dim3(128), 0, (hipStream_t)stream, G, s, reinterpret_cast<const bf16_t*>(w1), part, hid, K,
                      Gp);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int cvh_axpb(const float* a, float alpha, const float* b, float* out, int n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(axpb_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, alpha, b, out, n);
   CVH_CHECK_LAUNCH();
   return 0;
 }

@@ -97,8 +97,9 @@ def _dwx_eligible(dt, Cin, w1, hid, stride, act1) -> bool:
             and not (stride == 1 and Cin > 64) and hid % 8 == 0)
 
 
-def _gram(x, M, Kp):
-    """G = x^T x [Kp][Kp] and s = 1^T x [Kp] of a narrow [M][Kp] tensor (float32): one cvh_gemm_dw + one cvh_colsum"""
+def _gram(x, M, Kp, s_known=None):
+    """G = x^T x [Kp][Kp] and s = 1^T x [Kp] of a narrow [M][Kp] tensor (float32): one cvh_gemm_dw + one cvh_colsum (the latter skipped
+    when the producer of x already knows its column sums: `s_known`)"""
     dev = x.device
     if DW_SHAPE_LOG is not None:
         DW_SHAPE_LOG.append((int(M), 1, 1, 1, 1, int(Kp), 0, 1, 1, 1, 0, 1, int(Kp), int(Kp)))
@@ -107,6 +108,8 @@ def _gram(x, M, Kp):
     scr = _f32(max(n_scr, 1), dev)
     _lib.call("cvh_gemm_dw", _dt(x), _p(x), _p(x), None, Kp, 0, _p(G), int(M), 1, 1, 1, 1, 1, 1, 1, 0, 1, int(Kp), int(Kp), _p(scr), n_scr, 0,
               _stream())
+    if s_known is not None:
+        return G, s_known
     R = _lib.query("cvh_colreduce_rows", int(M), int(Kp))
     part = _f32(R * 2 * Kp, dev)
     s_ = _f32(Kp, dev)
@@ -159,7 +162,7 @@ def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp, P_ready=None, gram=None
 
 class InvertedResidualFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg, xsum=None):
         stride, use_res, training, act1, act2, mom, eps = cfg
         ops._check_dev(x)
         B, Cin, H, W = x.shape
@@ -186,7 +189,7 @@ class InvertedResidualFn(torch.autograd.Function):
             # in x), expansion + BN + act + depthwise conv in one kernel (csrc/dwx.hip)
             y1 = None
             if training:
-                gram = _gram(x, M1, Cin)
+                gram = _gram(x, M1, Cin, s_known=xsum)
                 part = _f32(2 * hid, dev)
                 _lib.call("cvh_gram_bn_stats", _p(gram[0]), _p(gram[1]), _p(wp1), _p(part), hid, Cin, Cin, _stream())
                 st1 = ops._bn_forward(x, M1, hid, part, 1, g1, b1, rm1, rv1, True, mom[0], eps[0])
@@ -224,12 +227,22 @@ class InvertedResidualFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.geom = (B, Cin, H, W, Ho, Wo, hid, Cout)
         ctx.params = (g1, b1, g2, b2, g3, b3)
+        # column sums of the block OUTPUT for the next block's statistics, without a pass over it: the output is a train-mode BatchNorm
+        # (+ the input on the residual path), so 1^T out = rows * beta3 (+ 1^T x).  (bf16 rounding of the stored output is zero-mean noise.)
+        osum = None
+        if use_x and training and (not use_res or gram is not None):
+            osum = _f32(Cout, dev)
+            _lib.call("cvh_axpb", _p(b3), float(M2), _p(gram[1]) if use_res else None, _p(osum), Cout, _stream())
+        ctx.has_osum = osum is not None
         ctx.use_x = use_x
         ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, *(gram if gram is not None else (None, None)))
+        if osum is not None:
+            ctx.mark_non_differentiable(osum)
+            return out, osum
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         stride, use_res, training, act1, act2, mom, eps = ctx.cfg
         B, Cin, H, W, Ho, Wo, hid, Cout = ctx.geom
         x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, gram_G, gram_s = ctx.saved_tensors
@@ -293,7 +306,7 @@ class InvertedResidualFn(torch.autograd.Function):
         elif use_res:
             dx = dout
         dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin, P_ready=P1, gram=gram)
-        return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None)
+        return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None, None)
 
 
 def inverted_residual(x, exp, dw, red, *, stride: int, use_res: bool):
@@ -301,5 +314,14 @@ def inverted_residual(x, exp, dw, red, *, stride: int, use_res: bool):
     (c1, n1, a1), (cd, n2, a2), (c3, n3, _) = exp, dw, red
     training = n1.training or not n1.track_running_stats
     cfg = (int(stride), bool(use_res), bool(training), int(a1), int(a2), (n1.momentum, n2.momentum, n3.momentum), (n1.eps, n2.eps, n3.eps))
-    return InvertedResidualFn.apply(x, c1.weight, n1.weight, n1.bias, n1.running_mean, n1.running_var, cd.weight, n2.weight, n2.bias,
-                                    n2.running_mean, n2.running_var, c3.weight, n3.weight, n3.bias, n3.running_mean, n3.running_var, cfg)
+    # `_cvh_colsum`: column sums a previous fused block attached to ITS output tensor (valid only for that very tensor object)
+    xsum = getattr(x, "_cvh_colsum", None)
+    if xsum is not None and (xsum.numel() != x.shape[1] or xsum.device != x.device):
+        xsum = None
+    res = InvertedResidualFn.apply(x, c1.weight, n1.weight, n1.bias, n1.running_mean, n1.running_var, cd.weight, n2.weight, n2.bias,
+                                   n2.running_mean, n2.running_var, c3.weight, n3.weight, n3.bias, n3.running_mean, n3.running_var, cfg, xsum)
+    if isinstance(res, tuple):
+        out, osum = res
+        out._cvh_colsum = osum
+        return out
+    return res

@@ -41,26 +41,6 @@ template <> struct DxTile<2> {  // 4 x 8 outputs <- 9 x 17 inputs
   static constexpr int OH = 4, OW = 8, IH = 9, IW = 17;
 };
 
-// A global load the compiler does not see as one (inline asm): the kernels below prefetch the NEXT tile's operands at the start of a tile and
-// consume them at the start of the following one, with this tile's result stores issued in between.  vmcnt retires in order, so the
-// prefetched data only needs the loads themselves (older than the stores) to have landed — `s_waitcnt vmcnt(<number of stores>)` — but the
-// compiler's wait insertion cannot count stores that sit behind exec-mask branches and emits a wait that drains the stores too: every tile
-// then exposes a full HBM write latency (measured with the phase knobs: the stores' 390 us ADDED to the 1600 us of dwx_fwd_kernel<1, 64>
-// instead of overlapping).  Hidden loads + one counted wait written by hand put the overlap back.  The caller must issue a matching
-// s_waitcnt before it reads the destination registers.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void hidden_load16(uint4& dst, const void* ptr) {
-  u32x4_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(ptr) : "memory");
-  dst = make_uint4(v.x, v.y, v.z, v.w);
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else static_assert(N == 0, "add the immediate");
-}
-
 __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
@@ -91,6 +71,8 @@ struct DwxFwdParams {
 
 // LDS pitch of the x tiles: dense rows for one 32-wide K step (2-way conflicts on the operand reads, 4 workgroups per CU), + 16 B otherwise
 template <int CIN> __host__ __device__ constexpr int dx_xp() { return 32 * ((CIN + 31) / 32) + (CIN <= 32 ? 0 : 8); }
+// x tile buffers of the forward kernel (see the tile loop)
+template <int CIN> __host__ __device__ constexpr int dx_xbuf() { return CIN <= 64 ? 2 : 1; }
 // waves per SIMD the register allocator is held to (= workgroups per CU the LDS footprint allows)
 #ifndef DX_OCC_A
 #define DX_OCC_A 4
@@ -113,8 +95,8 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
   constexpr int NPIX = TL::IH * TL::IW, NPB = (NPIX + 15) / 16, NOB = TL::OH * TL::OW / 16;
   constexpr int NXL = (NPIX * XC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [NPB * 16][XP]    block input, tile + halo (zero outside the image / past CIN)
-  bf16_t* at = xs + NPB * 16 * XP;                   // [4][NPB * 16][16] act(bn1(y1)): one dense [pixel][16 channels] image per wave
+  bf16_t* xs0 = reinterpret_cast<bf16_t*>(smem_raw);  // 2 x [NPB * 16][XP]  block input, tile + halo (zero outside the image / past CIN)
+  bf16_t* at = xs0 + dx_xbuf<CIN>() * NPB * 16 * XP;               // [4][NPB * 16][16]   act(bn1(y1)): one dense [pixel][16 channels] image per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int lb = xcd_chunk_id(blockIdx.x, gridDim.x);
@@ -123,7 +105,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
   const int hid = p.hid;
   bf16_t* atw = at + wave * (NPB * 16 * 16);
 
-  for (int i = tid; i < NPB * 16 * XP / 8; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < dx_xbuf<CIN>() * NPB * 16 * XP / 8; i += 256) reinterpret_cast<uint4*>(xs0)[i] = make_uint4(0, 0, 0, 0);
 
   bf16x8_t w1f[KS], wdf[5];
 #pragma unroll
@@ -190,7 +172,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
       const bf16_t* base = p.x + (((size_t)b * p.H + hi0) * p.W + wi0) * CIN;
       xok = xin;
 #pragma unroll
-      for (int it = 0; it < NXL; ++it) hidden_load16(xr[it], ((xin >> it) & 1u) ? base + xoff[it] : p.x);
+      for (int it = 0; it < NXL; ++it) xr[it] = *reinterpret_cast<const uint4*>(((xin >> it) & 1u) ? base + xoff[it] : p.x);
       return;
     }
     xok = 0;
@@ -202,23 +184,11 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
       const int hi = hi0 + pr, wi = wi0 + pc;
       const bool ok = i < NPIX * XC && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
       xok |= (ok ? 1u : 0u) << it;
-      hidden_load16(xr[it], p.x + (ok ? (((size_t)b * p.H + hi) * p.W + wi) * CIN + ck * 8 : (size_t)0));
+      xr[it] = *reinterpret_cast<const uint4*>(p.x + (ok ? (((size_t)b * p.H + hi) * p.W + wi) * CIN + ck * 8 : (size_t)0));
     }
   };
 
-  int tix = row_id;
-  if (tix < p.ntiles) load_x(tix);
-  bool counted = false;  // the previous tile issued exactly NOB unconditional stores after the prefetch
-  for (; tix < p.ntiles; tix += t_step) {
-    const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
-    const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
-    const int ho0 = th * TL::OH, wo0 = tw * TL::OW;
-    const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
-
-    __syncthreads();  // every wave is done with the previous x tile (first iteration: the zero fill is complete)
-    // the prefetched x tile: its loads are older than the previous tile's result stores (see hidden_load16)
-    if (counted) wait_vmcnt<NOB>();
-    else wait_vmcnt<0>();
+  auto stage_x = [&](bf16_t* xs) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < NXL; ++it) {
       const int i = tid + it * 256;
@@ -229,8 +199,36 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
         *reinterpret_cast<uint4*>(xs + px * XP + ck * 8) = v;
       }
     }
-    __syncthreads();
-    if (tix + t_step < p.ntiles && !(p.dbg & 16)) load_x(tix + t_step);  // next tile's input, in flight under this tile's arithmetic
+  };
+
+  // The x tile is double-buffered in LDS: the next tile's input is requested at the top of a tile, and each wave moves its share into
+  // the OTHER buffer right after its expansion phase, i.e. BEFORE this tile's result stores are issued.  (Consumed at the top of the
+  // next tile instead, the compiler's `s_waitcnt vmcnt(0)` - vmcnt counts loads and stores alike - drained the result stores too: one
+  // HBM write latency exposed per tile, 15-19 % of this kernel.)  One workgroup barrier per tile.
+  // (Cin > 64 keeps one buffer and consumes the prefetch at the top of the next tile: two buffers would halve its occupancy.)
+  constexpr bool DB = dx_xbuf<CIN>() == 2;
+  int tix = row_id, cur = 0;
+  if (tix < p.ntiles) {
+    load_x(tix);
+    if (DB) {
+      __syncthreads();  // the zero fills are complete
+      stage_x(xs0);
+    }
+  }
+  for (; tix < p.ntiles; tix += t_step) {
+    const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
+    const int th = t1 % p.tiles_h, b = t1 / p.tiles_h;
+    const int ho0 = th * TL::OH, wo0 = tw * TL::OW;
+    const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
+
+    const bf16_t* xs = xs0 + cur * (NPB * 16 * XP);
+    if (!DB) {
+      __syncthreads();  // every wave is done with the previous x tile (first iteration: the zero fill is complete)
+      stage_x(xs0);
+    }
+    __syncthreads();  // buffer `cur` is complete; every wave has left the previous tile (whose x lived in the other buffer)
+    const bool has_next = tix + t_step < p.ntiles && !(p.dbg & 16);
+    if (has_next) load_x(tix + t_step);  // next tile's input, in flight under this tile's expansion phase
 
     // pixels of the halo tile that lie inside the image (the conv's zero padding applies to the ACTIVATED tensor); interior tiles —
     // a wave-uniform test — skip the per-pixel arithmetic
@@ -291,6 +289,10 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
       epi(NPB - 1, accp);
     }
     wave_lds_sync();
+    if (DB) {
+      if (has_next) stage_x(xs0 + (cur ^ 1) * (NPB * 16 * XP));  // before the result stores below are issued (see above)
+      cur ^= 1;
+    }
 
     // ---- depthwise stencil on the matrix pipe (two accumulators: the five products of a block are not one dependent chain) ----
     if (!(p.dbg & 8)) {
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
       bf16_t* ybase = p.y2 + (((size_t)b * p.Ho + ho0) * p.Wo + wo0) * hid;
       const bool fast = wave_full && ho0 + TL::OH <= p.Ho && wo0 + TL::OW <= p.Wo && !(p.dbg & 2);
       auto epi = [&](int ob, const f32x2_t& lo, const f32x2_t& hi2) __attribute__((always_inline)) {
-        if (fast) {  // wave-uniform: exactly one store per block, no exec-mask branch around it (the counted wait above relies on that)
+        if (fast) {  // wave-uniform fast path: no per-lane bounds arithmetic
           *reinterpret_cast<uint2*>(ybase + yoff0 + ob * ystep) = make_uint2(f2bf_pk(lo[0], lo[1]), f2bf_pk(hi2[0], hi2[1]));
           s1[0] += lo;
           s1[1] += hi2;
@@ -339,12 +341,8 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
         phi = f32x2_t{a[2], a[3]} + f32x2_t{c[2], c[3]};
       }
       epi(NOB - 1, plo, phi);
-      counted = fast;
-    } else {
-      counted = false;
     }
   }
-  wait_vmcnt<0>();  // (hidden loads of a tile that was never consumed cannot exist: the prefetch is issued only when a next tile follows)
 
   if (p.stats_part != nullptr) {
     // a lane's 4 channels are shared with the 15 other pixel lanes of its group: fixed butterfly, then one lane per group writes
@@ -517,8 +515,8 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
       const bool ok = px < ND && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo && c0 + cg * 8 < hid;
       dok |= (ok ? 1u : 0u) << it;
       const size_t o = ok ? (((size_t)b * p.Ho + ho) * p.Wo + wo) * hid + c0 + cg * 8 : (size_t)0;
-      hidden_load16(gr[it], p.g_out + o);  // hidden from the compiler's wait insertion: see hidden_load16
-      hidden_load16(yr[it], (two_src ? p.y_out : p.g_out) + o);
+      gr[it] = *reinterpret_cast<const uint4*>(p.g_out + o);
+      yr[it] = *reinterpret_cast<const uint4*>((two_src ? p.y_out : p.g_out) + o);
     }
 #pragma unroll
     for (int it = 0; it < NXL; ++it) {
@@ -527,13 +525,12 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
       const int hi = hi0 + (px >> 4), wi = wi0 + (px & 15);
       const bool ok = i < 128 * XC && hi < p.H && wi < p.W;
       xok |= (ok ? 1u : 0u) << it;
-      hidden_load16(xr[it], p.x + (ok ? (((size_t)b * p.H + hi) * p.W + wi) * CIN + ck * 8 : (size_t)0));
+      xr[it] = *reinterpret_cast<const uint4*>(p.x + (ok ? (((size_t)b * p.H + hi) * p.W + wi) * CIN + ck * 8 : (size_t)0));
     }
   };
 
   int tix = row_id;
   if (tix < p.ntiles) load_tile(tix);
-  bool counted = false;  // the previous tile issued exactly 8 unconditional g1 stores after the prefetch
   const bool wave_full = cw + 16 <= hid;
   for (; tix < p.ntiles; tix += t_step) {
     const int tw = tix % p.tiles_w, t1 = tix / p.tiles_w;
@@ -542,9 +539,6 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
     bf16_t* gbase = p.g_in + (((size_t)b * p.H + hi0) * p.W + wi0) * hid;  // wave-uniform: the lanes add 32-bit offsets
 
     __syncthreads();  // every wave is done with the previous tile (first iteration: the zero fill and the coefficients are in place)
-    // the prefetched operands: their loads are older than the previous tile's g1 stores (see hidden_load16)
-    if (counted) wait_vmcnt<8>();
-    else wait_vmcnt<0>();
     const bool fast = wave_full && hi0 + 8 <= p.H && wi0 + 16 <= p.W;  // wave-uniform: every lane of every block stores
     {
       float ka[8], kb[8], kc[8];
@@ -681,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
       const uint32_t zm = pok ? 0xffffffffu : 0u;  // a pixel outside the image contributes nothing to dW
       *reinterpret_cast<uint2*>(zt + opx * DX_AP + 16 * wave + 4 * l4) = make_uint2(zw[0] & zm, zw[1] & zm);
       const int goff = (int)(__umul24(__umul24(r, p.W) + c, hid)) + cw + 4 * l4;  // elements from the tile's first pixel
-      if (fast) {  // exactly one store per block and no exec-mask branch around it: the counted wait at the top of the next tile relies on it
+      if (fast) {  // wave-uniform fast path: no per-lane bounds test
         *reinterpret_cast<uint2*>(gbase + goff) = make_uint2(gw[0], gw[1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -697,7 +691,6 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
         }
       }
     }
-    counted = fast;
     wave_lds_sync();
 
     // ---- depthwise weight gradient: diagonal of dy_shifted^T z, contraction over the tile's own pixels ----
@@ -738,7 +731,6 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
   }
 
   // ---- workgroup results: statistics and the diagonal of the dW accumulators ----
-  wait_vmcnt<0>();
   float t1[4] = {s1[0][0], s1[0][1], s1[1][0], s1[1][1]}, t2[4] = {s2[0][0], s2[0][1], s2[1][0], s2[1][1]};
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -809,7 +801,7 @@ __global__ void axpb_kernel(const float* __restrict__ a, float alpha, const floa
 template <int S, int CIN> size_t dwx_fwd_smem() {
   using TL = DxTile<S>;
   constexpr int NPB = (TL::IH * TL::IW + 15) / 16;
-  return (size_t)NPB * 16 * (dx_xp<CIN>() + DX_CC) * 2;
+  return (size_t)NPB * 16 * (dx_xbuf<CIN>() * dx_xp<CIN>() + DX_CC) * 2;
 }
 
 template <int S, int CIN> size_t dwx_bwd_smem() {

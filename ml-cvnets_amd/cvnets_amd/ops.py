@@ -190,6 +190,30 @@ def next_stream_id() -> int:
     return next(_stream_ids) & 0xFFFFFFFF
 
 
+# Debug export of the dropout draws (tests only: tests/test_dropout_step_gpu.py feeds the oracle the masks the kernels drew).
+_dropout_trace = None  # None, or a list that every dropout site of a forward appends (kind, stream id, p, shape of the masked tensor) to
+
+
+def trace_dropout_sites(sink):
+    """sink = a list: record every dropout draw of the following forwards in call order; None: stop recording"""
+    global _dropout_trace
+    _dropout_trace = sink
+
+
+def _trace_site(kind: str, sid: int, p: float, shape) -> None:
+    if _dropout_trace is not None and p > 0:
+        _dropout_trace.append((kind, int(sid), float(p), tuple(int(v) for v in shape)))
+
+
+def dropout_keep_scale(seed: torch.Tensor, stream_id: int, shape, p: float) -> torch.Tensor:
+    """The fp32 factor (0 or 1 / (1 - p)) that the element-wise dropout with this seed / stream id applies to a dense tensor of `shape`,
+    in MEMORY order: the standalone kernel run on ones (the GEMM epilogues index the same counter by row * N + column)."""
+    ones = torch.ones(tuple(shape), dtype=torch.float32, device=seed.device)
+    out = torch.empty_like(ones)
+    _lib.call("cvh_dropout", 0, _p(ones), _p(out), ones.numel(), float(p), _p(seed), int(stream_id), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # weight packing
 # ------------------------------------------------------------------------------------------------
@@ -949,6 +973,7 @@ class LinearAct(torch.autograd.Function):
 
 def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None, expose_pre=False, in_pre=None, in_act=ACT_NONE):
     sid = next_stream_id() if drop_p > 0 else 0
+    _trace_site("linear", sid, drop_p, (x2d.shape[0], weight.shape[0]))
     return LinearAct.apply(x2d, weight, bias, residual, in_pre, (int(act), float(drop_p), sid, bool(expose_pre), int(in_act)))
 
 
@@ -1138,6 +1163,7 @@ def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, 
     if key_padding_mask is not None:
         kpm = (key_padding_mask != 0).to(torch.uint8).contiguous()  # plumbing; any non-zero entry (True, 1, -inf) masks the key, as .to(torch.bool) does in the reference
     sid = next_stream_id() if drop_p > 0 else 0
+    _trace_site("attention", sid, drop_p, qkv2d.shape)
     return AttentionFn.apply(qkv2d, kpm, (int(heads), tuple(int(v) for v in seqmap), bool(causal), float(drop_p), sid))
 
 
@@ -1552,7 +1578,9 @@ class DropoutFn(torch.autograd.Function):
 def dropout(x, p: float, training: bool):
     if not training or p <= 0.0:
         return x
-    return DropoutFn.apply(x, float(p), next_stream_id())
+    sid = next_stream_id()
+    _trace_site("dropout", sid, p, x.shape)
+    return DropoutFn.apply(x, float(p), sid)
 
 
 class Dropout2dFn(torch.autograd.Function):

@@ -66,7 +66,7 @@ def grad_sample_fields(ref_grads):
     return out
 
 
-def build_reference_model(mode: str):
+def build_reference_model(mode: str, dropout: float = 0.0, classifier_dropout: float = 0.0):
     os.chdir(REF)
     import cvnets
     from options.utils import flatten_yaml_as_dict
@@ -81,11 +81,69 @@ def build_reference_model(mode: str):
     setattr(opts, "dev.device", "cpu")
     setattr(opts, "model.classification.mit.mode", mode)
     # parity configuration: dropout off (torch Philox streams are not reproducible across impls)
-    setattr(opts, "model.classification.mit.dropout", 0.0)
+    setattr(opts, "model.classification.mit.dropout", dropout)
     setattr(opts, "model.classification.mit.attn_dropout", 0.0)
     setattr(opts, "model.classification.mit.ffn_dropout", 0.0)
-    setattr(opts, "model.classification.classifier_dropout", 0.0)
+    setattr(opts, "model.classification.classifier_dropout", classifier_dropout)
     return cvnets.get_model(opts)
+
+
+def run_dropout_case(outdir, name="mobilevit_xxs_dropout_64_b4", mode="xx_small", batch=4, res=64, p=0.1):
+    """The shipped training configuration has mit.dropout = 0.1 and classifier_dropout = 0.1 (config/classification/imagenet/mobilevit.yaml).
+    The reference draws its masks from torch's generator; forward hooks on its Dropout layers record the factor (0 or 1 / (1 - p)) each
+    one applied, the oracle is run with exactly those factors (oracle.mobilevit_oracle.train_step(drop=...)) and must reproduce the
+    reference's logits, loss and gradients to fp32 round-off: this pins WHERE the oracle applies dropout.  The fixture keeps the keep bits."""
+    torch.manual_seed(0)
+    model = build_reference_model(mode, dropout=p, classifier_dropout=p)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=0)
+    model.load_state_dict(sd, strict=True)
+    x = seeded_input((batch, 3, res, res), seed=5)
+    y = seeded_labels(batch, 1000, seed=5)
+    model.train()
+    drop, hooks = {}, []
+    for nm, m in model.named_modules():
+        if type(m).__name__ == "Dropout" and m.p > 0:
+            if nm == "classifier.dropout":
+                key = "classifier"
+            elif nm.endswith(".pre_norm_mha.2"):
+                key = nm[: -len(".pre_norm_mha.2")] + ".mha"
+            elif nm.endswith(".pre_norm_ffn.5"):
+                key = nm[: -len(".pre_norm_ffn.5")] + ".ffn"
+            else:
+                raise RuntimeError("unexpected Dropout layer " + nm)
+            hooks.append(m.register_forward_hook(lambda m_, i, o, key=key: drop.__setitem__(key, (o.detach() != 0).float() / (1.0 - m_.p))))
+    torch.manual_seed(1234)
+    logits = model(x)
+    loss = torch.nn.functional.cross_entropy(logits, y, label_smoothing=0.1)
+    model.zero_grad()
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    ref_grads = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+    assert len(drop) == 2 * (2 + 4 + 3) + 1, sorted(drop)
+    o_logits, o_loss, o_grads, _ = orc.train_step(sd, x, y, mode=mode, drop=drop)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+    checks = {"logits": rel(o_logits, logits.detach()), "loss": abs(float(o_loss) - float(loss)),
+              "grad_worst_rel": max(rel(o_grads[k], ref_grads[k]) for k in ref_grads)}
+    # without the factors the same comparison must be far off (the hooks did record something that matters)
+    n_logits, _, _, _ = orc.train_step(sd, x, y, mode=mode)
+    checks["logits_without_masks"] = rel(n_logits, logits.detach())
+    print(name, {k: f"{v:.2e}" for k, v in checks.items()})
+    assert checks["logits"] < 1e-5 and checks["loss"] < 1e-5 and checks["grad_worst_rel"] < 2e-4 and checks["logits_without_masks"] > 1e-2, checks
+    names = list(ref_grads.keys())
+    out = {"logits_train": logits.detach().numpy(), "loss": np.float32(loss.item()), "grad_names": np.array(names),
+           "grad_norm": np.array([ref_grads[k].norm().item() for k in names], dtype=np.float64), "p": np.float32(p),
+           "oracle_vs_reference": np.array(json.dumps(checks))}
+    for k in FULL_GRADS:
+        out["grad::" + k] = ref_grads[k].numpy()
+    for k, f in drop.items():
+        out["keep::" + k] = np.packbits((f != 0).numpy().reshape(-1))
+        out["keepshape::" + k] = np.array(f.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
 
 
 def run_case(name, mode, batch, res, outdir):
@@ -694,6 +752,9 @@ if __name__ == "__main__":
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     torch.set_num_threads(8)
+    if "--dropout" in sys.argv:
+        run_dropout_case(outdir)
+        sys.exit(0)
     if "--detection" in sys.argv:
         run_detection_case(outdir)
         sys.exit(0)

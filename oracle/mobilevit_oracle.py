@@ -164,17 +164,23 @@ def multi_head_attention(sd, prefix, x: Tensor, num_heads: int,
 
 
 def transformer_encoder(sd, prefix, x: Tensor, num_heads: int, act: str = "swish",
-                        ln_eps: float = 1e-5, attn_mask=None, key_padding_mask=None) -> Tensor:
-    """TransformerEncoder.forward with dropout p=0 / drop_path Identity
-    (cvnets/modules/transformer.py:129-156)."""
+                        ln_eps: float = 1e-5, attn_mask=None, key_padding_mask=None, drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """TransformerEncoder.forward, drop_path Identity (cvnets/modules/transformer.py:129-156).  Dropout: p = 0 unless `drop` holds the
+    multiplicative factors (0 or 1 / (1 - p), shaped like x) of the two `Dropout(p=dropout)` layers, transformer.py:82 (after the
+    attention, key prefix + ".mha") and transformer.py:94 (after the second FFN linear, key prefix + ".ffn"); the generator that drew
+    them is outside the oracle (the tests export the draws of the path under test).  ffn_dropout (transformer.py:92) stays 0."""
     res = x
     y = layer_norm(sd, prefix + ".pre_norm_mha.0", x, ln_eps)
     y = multi_head_attention(sd, prefix + ".pre_norm_mha.1", y, num_heads, attn_mask, key_padding_mask)
+    if drop is not None:
+        y = y * drop[prefix + ".mha"]
     x = y + res
     y = layer_norm(sd, prefix + ".pre_norm_ffn.0", x, ln_eps)
     y = F.linear(y, sd[prefix + ".pre_norm_ffn.1.weight"], sd[prefix + ".pre_norm_ffn.1.bias"])
     y = F.silu(y) if act == "swish" else F.gelu(y)
     y = F.linear(y, sd[prefix + ".pre_norm_ffn.4.weight"], sd[prefix + ".pre_norm_ffn.4.bias"])
+    if drop is not None:
+        y = y * drop[prefix + ".ffn"]
     return x + y
 
 
@@ -213,14 +219,14 @@ def folding(patches: Tensor, info: Dict, ph: int, pw: int) -> Tensor:
 
 
 def mobilevit_block(sd, prefix, x: Tensor, n_blocks: int, num_heads: int, training: bool,
-                    bn_state, ph: int = 2, pw: int = 2, taps: Optional[Dict] = None) -> Tensor:
+                    bn_state, ph: int = 2, pw: int = 2, taps: Optional[Dict] = None, drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """MobileViTBlock.forward_spatial  (cvnets/modules/mobilevit_block.py:269-288)."""
     res = x
     fm = conv_bn_act(sd, prefix + ".local_rep.conv_3x3", x, training=training, bn_state=bn_state)
     fm = conv_bn_act(sd, prefix + ".local_rep.conv_1x1", fm, use_norm=False, use_act=False)
     patches, info = unfolding(fm, ph, pw)
     for i in range(n_blocks):
-        patches = transformer_encoder(sd, f"{prefix}.global_rep.{i}", patches, num_heads)
+        patches = transformer_encoder(sd, f"{prefix}.global_rep.{i}", patches, num_heads, drop=drop)
     patches = layer_norm(sd, f"{prefix}.global_rep.{n_blocks}", patches)
     if taps is not None:
         taps[prefix + ".patches"] = patches
@@ -232,11 +238,12 @@ def mobilevit_block(sd, prefix, x: Tensor, n_blocks: int, num_heads: int, traini
 
 def mobilevit_forward(sd: Dict[str, Tensor], x: Tensor, mode: str = "small", num_heads: int = 4,
                       training: bool = True, bn_state: Optional[BNState] = None,
-                      taps: Optional[Dict] = None) -> Tensor:
+                      taps: Optional[Dict] = None, drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """MobileViT.forward -> BaseImageEncoder.forward_classifier/extract_features
     (cvnets/models/classification/mobilevit.py:26-125; base_image_encoder.py:261-283);
-    classifier = GlobalPool(mean) -> LinearLayer (mobilevit.py:106-119, global_pool.py:60-71).
-    Dropout layers are p=0 (parity configuration)."""
+    classifier = GlobalPool(mean) -> [Dropout] -> LinearLayer (mobilevit.py:106-119, global_pool.py:60-71).
+    Dropout layers are p=0 (parity configuration) unless `drop` supplies the factors every Dropout layer multiplies by: see
+    transformer_encoder for the keys of the transformer layers, "classifier" for mobilevit.py:110-113."""
     cfg = mobilevit_config(mode)
     exp = cfg["exp"]
     x = conv_bn_act(sd, "conv_1", x, stride=2, training=training, bn_state=bn_state)
@@ -255,11 +262,13 @@ def mobilevit_forward(sd: Dict[str, Tensor], x: Tensor, mode: str = "small", num
         c = cfg[name]
         x = inverted_residual(sd, f"layer_{li}.0", x, cin, c["out"], 2, exp, training, bn_state)
         cin = c["out"]
-        x = mobilevit_block(sd, f"layer_{li}.1", x, c["nblk"], num_heads, training, bn_state, taps=taps)
+        x = mobilevit_block(sd, f"layer_{li}.1", x, c["nblk"], num_heads, training, bn_state, taps=taps, drop=drop)
         if taps is not None:
             taps[f"layer_{li}"] = x
     x = conv_bn_act(sd, "conv_1x1_exp", x, training=training, bn_state=bn_state)
     x = torch.mean(x, dim=[-2, -1])
+    if drop is not None and "classifier" in drop:
+        x = x * drop["classifier"]
     return F.linear(x, sd["classifier.fc.weight"], sd["classifier.fc.bias"])
 
 
@@ -270,13 +279,13 @@ def cross_entropy(logits: Tensor, target: Tensor, label_smoothing: float = 0.1) 
 
 
 def train_step(sd: Dict[str, Tensor], x: Tensor, y: Tensor, mode: str = "small",
-               label_smoothing: float = 0.1):
+               label_smoothing: float = 0.1, drop: Optional[Dict[str, Tensor]] = None):
     """One fwd + loss + bwd of the hot path (engine/training_engine.py:257-287 without the
     optimizer).  Returns (logits, loss, grads-by-name, updated BN running stats)."""
     params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k)
               for k, v in sd.items()}
     st = BNState()
-    logits = mobilevit_forward(params, x, mode=mode, training=True, bn_state=st)
+    logits = mobilevit_forward(params, x, mode=mode, training=True, bn_state=st, drop=drop)
     loss = cross_entropy(logits, y, label_smoothing)
     names = [k for k, v in params.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [params[k] for k in names])

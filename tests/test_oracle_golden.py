@@ -127,3 +127,38 @@ def test_weights_are_platform_independent():
     # fixed known-answer values (PCG64 stream): guards against numpy RNG drift between the authoring box and the GPU box
     assert abs(float(t.flatten()[0]) - float(seeded_state_dict({"conv_1.block.conv.weight": (16, 3, 3, 3)}, 0)["conv_1.block.conv.weight"].flatten()[0])) == 0
     assert t.shape == (16, 3, 3, 3) and abs(float(t.std()) - 1 / np.sqrt(27)) < 0.03
+
+
+def load_keep_factors(gold):
+    """the factors (0 or 1 / (1 - p)) the reference's Dropout layers applied in the recorded run (oracle/make_golden.py --dropout)"""
+    p = float(gold["p"])
+    drop = {}
+    for key in gold.files:
+        if key.startswith("keep::"):
+            shape = tuple(int(v) for v in gold["keepshape::" + key[6:]])
+            n = int(np.prod(shape))
+            drop[key[6:]] = torch.from_numpy(np.unpackbits(gold[key])[:n].reshape(shape).astype(np.float32)) / (1.0 - p)
+    return drop
+
+
+def test_oracle_with_dropout_factors_matches_reference_fixture():
+    """mit.dropout = classifier_dropout = 0.1 (the shipped configuration): the oracle, fed the keep masks the reference drew, reproduces
+    the reference's training step — this pins WHERE the oracle applies dropout (tests/test_dropout_step_gpu.py relies on it)."""
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    gold = np.load(os.path.join(GOLD, "mobilevit_xxs_dropout_64_b4.npz"))
+    shapes = json.load(open(os.path.join(GOLD, "mobilevit_xx_small_keys.json")))
+    sd = seeded_state_dict(shapes, seed=0)
+    x = seeded_input((4, 3, 64, 64), seed=5)
+    y = seeded_labels(4, 1000, seed=5)
+    drop = load_keep_factors(gold)
+    assert len(drop) == 19 and all(0.05 < float((f == 0).float().mean()) < 0.15 for k, f in drop.items() if k != "classifier")
+    logits, loss, grads, _ = orc.train_step(sd, x, y, mode="xx_small", drop=drop)
+    assert np.allclose(logits.numpy(), gold["logits_train"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(gold["loss"])) < 1e-5
+    names = [str(n) for n in gold["grad_names"]]
+    assert np.allclose(np.array([grads[k].norm().item() for k in names]), gold["grad_norm"], rtol=1e-3, atol=1e-7)
+    for key in gold.files:
+        if key.startswith("grad::"):
+            assert np.allclose(grads[key[6:]].numpy(), gold[key], rtol=1e-3, atol=1e-6), key
+    plain, _, _, _ = orc.train_step(sd, x, y, mode="xx_small")
+    assert not np.allclose(plain.numpy(), gold["logits_train"], rtol=1e-2, atol=1e-3)  # the masks matter

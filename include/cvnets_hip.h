@@ -205,6 +205,18 @@ int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float* in_stats,
                 const float* ca, const float* cb, const float* cc, const void* wd, void* g_in, float* stats_part, float* dw_part,
                 int B, int H, int W, int Ho, int Wo, int Cin, int hid, int stride, void* stream);
 
+/* Conv2d(1x1).backward of the block's PROJECTION conv (cvnets/modules/mobilenetv2.py:208-219; it sits behind depthwise -> BatchNorm -> SiLU)
+ * from ONE pass over the 4x-wide y2 [M][hid] (bf16, SiLU; csrc/ir_pb.hip):
+ *   g2 = (dy3 W3) * act'(bn2(y2)) stored [M][hid]; stats_part[rows][2][hid] = (sum g2, sum g2 * xhat2) for cvh_bn_bwd_finalize;
+ *   dw_part[rows][Cout][hid] = partial dW3 = dy3^T act(bn2(y2)) (sum the rows with cvh_sum_partials / cvh_reduce_multi).
+ * dy = dy3 [M][Cout], or — y3 != NULL — the block's output gradient with dy3 = c3[0] * dy + c3[1] * y3 + c3[2] formed on load (c3 = the
+ * [3][Cout] coefficients of cvh_bn_bwd_finalize for the projection's BatchNorm: no cvh_bn_bwd_apply pass).  st2 = [4][hid] mean, invstd,
+ * scale, shift; w3t = [hid][Cout] transposed pack (cvh_weight_pack mode 1).  Covers hid % 64 == 0, Cout in {32, 64, 96, 128, 160},
+ * M >= 4096: rows = cvh_ir_pb_rows() is 0 otherwise (callers fall back to cvh_pw_gemm_dw_bn + cvh_pw_gemm_bn). */
+int cvh_ir_pb_rows(int M, int hid, int Cout);
+int cvh_ir_pb(int dtype, const void* dy, const void* y3, const float* c3, const void* y2, const float* st2, int act, const void* w3t, void* g2,
+              float* stats_part, float* dw_part, int M, int hid, int Cout, void* stream);
+
 /* Linear side of a BatchNorm link (y = x W^T in front of the BatchNorm, e.g. the 1x1 expansion conv): with coef[3][N] = (ca, cb, cc) of
  * cvh_bn_bwd_finalize and g = dz * act'(bn(y)),
  *   dX = g (diag(ca) W) + x (W^T diag(cb) W) + 1 (cc^T W): cvh_bn_dx_weights writes wcat[pad8(K)][N + pad8(K)] (`dtype`) and

@@ -39,6 +39,8 @@ SIGNATURES = {
     "cvh_gram_bn_stats": [P, P, P, P, I, I, I, P],
     "cvh_dwx_fwd": [I, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P],
     "cvh_dwx_bwd": [I, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "cvh_ir_pb_rows": [I, I, I],
+    "cvh_ir_pb": [I, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
     "cvh_ir_red_fwd_rows": [L, I, I],
     "cvh_ir_red_fwd": [I, P, P, P, I, P, P, P, L, I, I, P],
     "cvh_ir_exp_bwd": [I, P, P, P, P, P, P, P, L, I, I, P],

@@ -27,6 +27,9 @@ _IR_RED_FUSED = __import__("os").environ.get("CVH_IR_RED_FUSED", "1") != "0"
 # expansion + depthwise as ONE kernel per direction with y1 recomputed from the narrow input (csrc/dwx.hip): 0 = off, 1 = forward and
 # backward, "fwd" = forward only (the backward then rebuilds y1 with the expansion GEMM and runs cvh_dwconv_bn_bwd: A/B runs, tests)
 _IR_X = __import__("os").environ.get("CVH_IR_X", "1")
+# projection backward (dW3, g2, statistics) from ONE pass over y2, with the BatchNorm-backward apply of the block output folded into its
+# operand load (csrc/ir_pb.hip); 0 = the dW GEMM + dX GEMM pair
+_IR_PB = __import__("os").environ.get("CVH_IR_PB", "1") != "0"
 DW_SHAPE_LOG = None  # set to a list to record the plain dW GEMMs launched from this module (bench.py)
 
 
@@ -251,14 +254,34 @@ class InvertedResidualFn(torch.autograd.Function):
         dout = ops.as_nhwc(dout)
         dev, dt = dout.device, dout.dtype
         M1, M2 = B * H * W, B * Ho * Wo
-        # BatchNorm of the projection conv: narrow tensor, standalone passes
-        dy3, dg3, db3 = ops._bn_backward(y3, dout, st3, g3, ACT_NONE, M2, Cout, training, beta=pb3)
-        # dW3 = dy3^T x act(bn2(y2))
-        dw3 = _pw_weight_grad(dy3, (0,), y2, (1, None, st2[2], st2[3], None, act2), w3, M2, Cout, hid)
-        # g2 = (dy3 W3) * act2'(bn2(y2)) with (sum g2, sum g2*xhat2) from the same epilogue
+        Rp = 0
+        if _IR_PB and dt == torch.bfloat16 and act2 == ops.ACT_SILU and w3.shape[1] == hid:
+            Rp = _lib.query("cvh_ir_pb_rows", M2, hid, Cout)
         g2t = torch.empty_like(y2)
-        part, R = _pw_gemm(dy3, None, Cout, ops.pack_weight(w3, dt, 1), g2t, M2, hid, e_mode=1, e_aux=y2, e_stats=st2, e_act=act2,
-                           want_stats=True)
+        if Rp > 0:
+            # BatchNorm of the projection conv: statistics pass over the narrow (dout, y3) only — dy3 = ca dout + cb y3 + cc is formed by the
+            # consumer on load; then dW3, g2 and (sum g2, sum g2*xhat2) from ONE pass over y2 (csrc/ir_pb.hip)
+            coef3, dg3, db3 = ops._bn_backward_coeffs(y3, dout, st3, g3, ACT_NONE, M2, Cout, training, beta=pb3)
+            part = _f32(Rp * 2 * hid, dev)
+            dw_part = _f32(Rp * Cout * hid, dev)
+            wp3t = ops.pack_weight(w3, dt, 1)  # alive across the launch (uncached packs are temporaries)
+            _lib.call("cvh_ir_pb", _dt(y2), _p(dout), _p(y3), _p(coef3), _p(y2), _p(st2), act2, _p(wp3t), _p(g2t), _p(part), _p(dw_part), M2, hid,
+                      Cout, _stream())
+            sink3 = ops._grad_sink(w3)
+            dw3 = None if sink3 is not None else torch.empty(w3.shape, dtype=torch.float32, device=dev)
+            n3 = Cout * hid
+            if not (sink3 is not None and ops.defer_reduce(dw_part, sink3, Rp, n3, n3)):
+                _lib.call("cvh_sum_partials", _p(dw_part), Rp, n3, n3, _p(sink3 if sink3 is not None else dw3), 1.0, 1 if sink3 is not None else 0,
+                          _stream())
+            R = Rp
+        else:
+            # BatchNorm of the projection conv: narrow tensor, standalone passes
+            dy3, dg3, db3 = ops._bn_backward(y3, dout, st3, g3, ACT_NONE, M2, Cout, training, beta=pb3)
+            # dW3 = dy3^T x act(bn2(y2))
+            dw3 = _pw_weight_grad(dy3, (0,), y2, (1, None, st2[2], st2[3], None, act2), w3, M2, Cout, hid)
+            # g2 = (dy3 W3) * act2'(bn2(y2)) with (sum g2, sum g2*xhat2) from the same epilogue
+            part, R = _pw_gemm(dy3, None, Cout, ops.pack_weight(w3, dt, 1), g2t, M2, hid, e_mode=1, e_aux=y2, e_stats=st2, e_act=act2,
+                               want_stats=True)
         coef2, dg2, db2 = _bwd_finalize(part, R, hid, M2, g2, st2, pg2, pb2, training)
         # depthwise backward in one pass: dy2 formed on load, g1 out, dW of the depthwise conv, statistics of g1
         g1t = ops.nhwc_empty(B, hid, H, W, dt, dev)

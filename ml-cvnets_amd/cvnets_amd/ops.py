@@ -591,8 +591,9 @@ def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentu
     return stats
 
 
-def _bn_backward(y, dout, stats, gamma, act, rows, C, training, beta=None):
-    """returns (dy_raw, dgamma, dbeta); dgamma/dbeta are None when they were added in place into gamma.grad / beta.grad."""
+def _bn_backward_coeffs(y, dout, stats, gamma, act, rows, C, training, beta=None):
+    """The statistics half of the BatchNorm backward: returns (coeff[3][C], dgamma, dbeta) with dy_raw = coeff[0] * (dout * act'(bn(y))) +
+    coeff[1] * y + coeff[2] left to the consumer (cvh_bn_bwd_apply, or an operand load that forms it: csrc/ir_pb.hip)."""
     dev = y.device
     R = _lib.query("cvh_colreduce_rows", rows, C)
     part = _f32(R * 2 * C, dev)
@@ -607,6 +608,12 @@ def _bn_backward(y, dout, stats, gamma, act, rows, C, training, beta=None):
               1 if inplace else 0, _p(dgamma), _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
     if inplace:
         dgamma = dbeta = None
+    return coeff, dgamma, dbeta
+
+
+def _bn_backward(y, dout, stats, gamma, act, rows, C, training, beta=None):
+    """returns (dy_raw, dgamma, dbeta); dgamma/dbeta are None when they were added in place into gamma.grad / beta.grad."""
+    coeff, dgamma, dbeta = _bn_backward_coeffs(y, dout, stats, gamma, act, rows, C, training, beta=beta)
     dy = torch.empty_like(y)
     _lib.call("cvh_bn_bwd_apply", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), act, _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _p(dy),
               rows, C, _stream())

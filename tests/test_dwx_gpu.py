@@ -127,21 +127,65 @@ def test_dwx_bwd_matches_autograd(B, H, W, Cin, hid, stride, two_src):
     assert float((st[1] - (gf * xh).sum(0)).abs().max() / ((gf * xh).abs().sum(0).max() + 1e-6)) < 2e-3
 
 
+@pytest.mark.parametrize("M,hid,Cout,two_src", [(4096 + 77, 64, 32, False), (9000, 256, 64, True), (5000, 256, 96, False), (4200, 384, 128, True),
+                                                 (4100, 512, 160, True), (20000, 128, 64, False), (70001, 256, 64, True)])
+def test_ir_pb_projection_backward(M, hid, Cout, two_src):
+    """cvh_ir_pb (csrc/ir_pb.hip): g2 = (dy3 W3) * act'(bn2(y2)), its BatchNorm-backward statistics and dW3 = dy3^T act(bn2(y2)) from one pass
+    over y2, dy3 optionally formed on load from (dout, y3, coefficients) — against fp32 matmuls on the same bf16-rounded operands."""
+    from cvnets_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(5 + hid + Cout)
+    y2 = torch.randn(M, hid, device=DEV, generator=g).bfloat16()
+    dout = (torch.randn(M, Cout, device=DEV, generator=g) * 0.5).bfloat16()
+    y3 = torch.randn(M, Cout, device=DEV, generator=g).bfloat16()
+    c3 = torch.stack([torch.rand(Cout, device=DEV, generator=g) + 0.5, torch.randn(Cout, device=DEV, generator=g) * 0.2,
+                      torch.randn(Cout, device=DEV, generator=g) * 0.1]).contiguous()
+    dy3 = (c3[0] * dout.float() + c3[1] * y3.float() + c3[2]).bfloat16().float() if two_src else dout.float()
+    mean2 = torch.randn(hid, device=DEV, generator=g) * 0.2
+    invstd2 = torch.rand(hid, device=DEV, generator=g) + 0.7
+    sc2 = torch.rand(hid, device=DEV, generator=g) + 0.5
+    sh2 = torch.randn(hid, device=DEV, generator=g) * 0.3
+    st2 = torch.stack([mean2, invstd2, sc2, sh2]).contiguous()
+    w3 = (torch.randn(Cout, hid, device=DEV, generator=g) * hid ** -0.5).bfloat16()
+    yh = y2.float() * sc2 + sh2
+    sg = torch.sigmoid(yh)
+    z2, f1, xh = yh * sg, sg * (1 + yh * (1 - sg)), (y2.float() - mean2) * invstd2
+    g2_ref = (dy3 @ w3.float()) * f1
+    dw_ref = dy3.t() @ z2.bfloat16().float()  # z2 enters the product as a bf16 operand
+    R = _lib.query("cvh_ir_pb_rows", M, hid, Cout)
+    assert R > 0
+    g2 = torch.full((M, hid), float("nan"), device=DEV, dtype=torch.bfloat16)
+    part = torch.full((R, 2, hid), float("nan"), device=DEV)
+    dwp = torch.full((R, Cout, hid), float("nan"), device=DEV)
+    w3t = w3.t().contiguous()
+    _lib.call("cvh_ir_pb", 1, dout.data_ptr(), y3.data_ptr() if two_src else None, c3.data_ptr() if two_src else None, y2.data_ptr(), st2.data_ptr(), 1,
+              w3t.data_ptr(), g2.data_ptr(), part.data_ptr(), dwp.data_ptr(), M, hid, Cout, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not torch.isnan(g2.float()).any() and not torch.isnan(part).any() and not torch.isnan(dwp).any()
+    assert float((g2.float() - g2_ref).abs().max() / g2_ref.abs().max()) < 8e-3
+    dw = dwp.sum(0)
+    assert float((dw - dw_ref).abs().max() / dw_ref.abs().max()) < 3e-3
+    st = part.sum(0)
+    assert float((st[0] - g2_ref.sum(0)).abs().max() / g2_ref.abs().sum(0).max()) < 2e-3
+    assert float((st[1] - (g2_ref * xh).sum(0)).abs().max() / (g2_ref * xh).abs().sum(0).max()) < 2e-3
+
+
 @pytest.mark.parametrize("Cin,Cout,stride,hw", [(64, 64, 1, 32), (32, 64, 2, 48), (16, 32, 1, 40), (96, 128, 2, 16)])
 def test_inverted_residual_with_and_without_recomputed_expansion(Cin, Cout, stride, hw):
-    """the whole fused block, forward + backward, with y1 recomputed (csrc/dwx.hip) against the y1-storing kernels"""
+    """the whole fused block, forward + backward, with y1 recomputed (csrc/dwx.hip; "1": one-pass projection backward csrc/ir_pb.hip as
+    well, "gemm": the projection backward as a dW GEMM + dX GEMM pair) against the y1-storing kernels"""
     from cvnets_amd import fused, layers, ops
     from cvnets_amd.modules import InvertedResidual
     opts = layers.default_opts()
     x = torch.randn(6, Cin, hw, hw + 8, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     go = None
     res = {}
-    saved = fused._IR_X
-    for mode in ("1", "fwd", "0"):
+    saved, saved_pb = fused._IR_X, fused._IR_PB
+    for mode in ("1", "gemm", "fwd", "0"):
         torch.manual_seed(5)
         m = InvertedResidual(opts, Cin, Cout, stride=stride, expand_ratio=4).to(DEV).train()
         xin = x.clone().requires_grad_(True)
-        fused._IR_X = mode
+        fused._IR_X = "1" if mode == "gemm" else mode
+        fused._IR_PB = mode == "1"
         ops.set_compute_dtype(torch.bfloat16)
         try:
             out = m(xin)
@@ -150,7 +194,7 @@ def test_inverted_residual_with_and_without_recomputed_expansion(Cin, Cout, stri
             out.backward(go)
             ops.finish_backward()
         finally:
-            fused._IR_X = saved
+            fused._IR_X, fused._IR_PB = saved, saved_pb
             ops.set_compute_dtype(None)
         torch.cuda.synchronize()
         res[mode] = [out.detach().float(), xin.grad.float()] + [p_.grad.float().clone() for p_ in m.parameters()] + \
@@ -158,7 +202,7 @@ def test_inverted_residual_with_and_without_recomputed_expansion(Cin, Cout, stri
     # the y1-storing path rounds y1 to bf16, the recomputing one keeps it in fp32: both are bf16-level results, and the per-channel BatchNorm
     # gradients of the expansion (sums over all pixels with heavy cancellation: the tensors with the largest bf16 error in the whole model,
     # tests/test_bf16_parity_gpu.py) move by a few per cent between them -> 1-D tensors get the looser bound
-    for mode in ("1", "fwd"):
+    for mode in ("1", "gemm", "fwd"):
         for a, b in zip(res[mode], res["0"]):
             scale = float(b.abs().max()) + 1e-6
             tol = 1e-1 if a.dim() == 1 else 2e-2

@@ -143,13 +143,10 @@ extern "C" int cvh_bn_dx_weights(int dtype, const float* w, const float* coef, v
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = ((size_t)N * (K + 1) + 2 * (size_t)N) * sizeof(float);
   if (lds <= 96 * 1024 && (dtype == CVH_DT_BF16 || dtype == CVH_DT_F32)) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bn_dx_weights_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bn_dx_weights_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    static DynSmemAttr attr_b, attr_f;
+    hipError_t e = attr_b.ensure(reinterpret_cast<const void*>(bn_dx_weights_lds_kernel<bf16_t>), 96 * 1024);
+    if (e == hipSuccess) e = attr_f.ensure(reinterpret_cast<const void*>(bn_dx_weights_lds_kernel<float>), 96 * 1024);
+    if (e != hipSuccess) return (int)e;
     if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((bn_dx_weights_lds_kernel<bf16_t>), dim3(Kp), dim3(256), lds, st, w, coef, (bf16_t*)wcat, bias, N, K, Kp);
     else hipLaunchKernelGGL((bn_dx_weights_lds_kernel<float>), dim3(Kp), dim3(256), lds, st, w, coef, (float*)wcat, bias, N, K, Kp);
     CVH_CHECK_LAUNCH();

@@ -3,6 +3,7 @@
 // all arithmetic accumulates in fp32.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <type_traits>
 
@@ -384,6 +385,24 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_BIG_MIN_N 16 /* narrowest output the ragged direct-to-LDS GEMM takes (0: the default, 192) */
 #define CVH_TUNE_MAX 24
 int cvh_tune_get(int key);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: cache of the size already granted, one slot per device
+// (a process that touches a second GPU must set it there too).  One static instance per kernel instantiation.
+struct DynSmemAttr {
+  std::atomic<size_t> granted[16];
+  DynSmemAttr() { for (auto& g : granted) g.store(0); }
+  hipError_t ensure(const void* fn, size_t smem) {
+    if (smem <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& g = granted[dev & 15];
+    if (smem <= g.load(std::memory_order_acquire)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess) g.store(smem, std::memory_order_release);
+    return e;
+  }
+};
+
 
 #define CVH_CHECK_LAUNCH()                         \
   do {                                             \

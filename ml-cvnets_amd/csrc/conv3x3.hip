@@ -266,20 +266,12 @@ int launch_conv3x3(const ConvGemmParams& p, int rows, hipStream_t st) {
   const int nf = p.N / 32;
   int grid = g.ntiles < 512 ? g.ntiles : 512;
   if (p.stats_part != nullptr && rows > 0 && grid > rows) grid = rows;
-  static size_t attr3 = 0, attr4 = 0;
+  static DynSmemAttr attr3, attr4;
   if (nf == 3) {
-    if (smem > 64 * 1024 && smem > attr3) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return (int)e;
-      attr3 = smem;
-    }
+    if (hipError_t e = attr3.ensure(reinterpret_cast<const void*>(conv3x3_kernel<3>), smem); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(conv3x3_kernel<3>, dim3(grid), dim3(256), smem, st, p, g);
   } else {
-    if (smem > 64 * 1024 && smem > attr4) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return (int)e;
-      attr4 = smem;
-    }
+    if (hipError_t e = attr4.ensure(reinterpret_cast<const void*>(conv3x3_kernel<4>), smem); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(conv3x3_kernel<4>, dim3(grid), dim3(256), smem, st, p, g);
   }
   CVH_CHECK_LAUNCH();

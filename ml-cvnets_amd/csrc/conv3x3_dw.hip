@@ -221,13 +221,8 @@ int launch_conv3x3_dw(const GemmTNParams& p, hipStream_t st) {
   if (!dw3_plan(p, g, smem, nb, cbmax) || p.part == nullptr) return -2;
 #define D3_LAUNCH(NB_, CB_)                                                                                                             \
   do {                                                                                                                                  \
-    static size_t attr = 0;                                                                                                             \
-    if (smem > 64 * 1024 && smem > attr) {                                                                                              \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_dw_kernel<NB_, CB_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)smem);                                                                                    \
-      if (e != hipSuccess) return (int)e;                                                                                               \
-      attr = smem;                                                                                                                      \
-    }                                                                                                                                   \
+    static DynSmemAttr attr;                                                                                                            \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(conv3x3_dw_kernel<NB_, CB_>), smem); e != hipSuccess) return (int)e;  \
     hipLaunchKernelGGL((conv3x3_dw_kernel<NB_, CB_>), dim3(g.rows * g.nslab), dim3(D3_THREADS), smem, st, p, g);                        \
   } while (0)
   if (nb == 6) D3_LAUNCH(6, 3);

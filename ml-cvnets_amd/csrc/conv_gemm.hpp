@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 // =============================================================================================
 // host-side tally of the conv_gemm_kernel family (bench.py, cvh_stream_counters): launches and their algorithmic bytes — the input tensor(s),
 // the output and every [M][N] epilogue operand once, 2 (bf16) / 4 (f32) bytes per element; defined in gemm.hip
-extern long long g_cg_launches, g_cg_bytes;
+extern std::atomic<long long> g_cg_launches, g_cg_bytes;
 
 template <typename T, int NF, int BK, int FX, int WP = 0>
 static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {

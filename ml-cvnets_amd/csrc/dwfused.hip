@@ -498,12 +498,8 @@ template <typename T, int S> static size_t dwf_bwd_smem() {
   return (size_t)(TL::DH * TL::DW) * dwf_pitch<T>() * sizeof(T) + 27 * DWF_CC * sizeof(float);
 }
 
-template <typename K> static int dwf_launch(K kern, size_t smem, dim3 grid, hipStream_t st, const DwfParams& p, bool* attr_set) {
-  if (smem > 64 * 1024 && !*attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    *attr_set = true;
-  }
+template <typename K> static int dwf_launch(K kern, size_t smem, dim3 grid, hipStream_t st, const DwfParams& p, DynSmemAttr* attr) {
+  if (hipError_t e = attr->ensure(reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   CVH_CHECK_LAUNCH();
   return 0;
@@ -545,7 +541,7 @@ extern "C" int cvh_dwconv_bn_fwd(int dtype, const void* x, const cvh_operand_xf*
   dim3 grid;
   dwf_plan(p, stride, &grid);
   hipStream_t st = (hipStream_t)stream;
-  static bool a0 = false, a1 = false, a2 = false, a3 = false;
+  static DynSmemAttr a0, a1, a2, a3;
   if (dtype == CVH_DT_BF16) {
     if (stride == 1) return dwf_launch(dwf_fwd_kernel<bf16_t, 1>, dwf_fwd_smem<bf16_t, 1>(), grid, st, p, &a0);
     return dwf_launch(dwf_fwd_kernel<bf16_t, 2>, dwf_fwd_smem<bf16_t, 2>(), grid, st, p, &a1);
@@ -572,7 +568,7 @@ extern "C" int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand
   dim3 grid;
   dwf_plan(p, stride, &grid);
   hipStream_t st = (hipStream_t)stream;
-  static bool a0 = false, a1 = false, a2 = false, a3 = false;
+  static DynSmemAttr a0, a1, a2, a3;
   if (dtype == CVH_DT_BF16) {
     if (stride == 1) return dwf_launch(dwf_bwd_kernel<bf16_t, 1>, dwf_bwd_smem<bf16_t, 1>(), grid, st, p, &a0);
     return dwf_launch(dwf_bwd_kernel<bf16_t, 2>, dwf_bwd_smem<bf16_t, 2>(), grid, st, p, &a1);

@@ -863,18 +863,11 @@ extern "C" int cvh_dwx_fwd(int dtype, const void* x, const void* w1, const float
   p.dbg = cvh_tune_get(17);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
 #define DX_FWD(S_, C_)                                                                                                                    \
   do {                                                                                                                                    \
     const size_t smem = dwx_fwd_smem<S_, C_>();                                                                                           \
-    static unsigned attr_done = 0; /* one bit per device: the attribute is per device */                                                  \
-    if (smem > 64 * 1024 && !((attr_done >> (dev & 31)) & 1u)) {                                                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwx_fwd_kernel<S_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)smem);                                                                                      \
-      if (e != hipSuccess) return (int)e;                                                                                                 \
-      attr_done |= 1u << (dev & 31);                                                                                                      \
-    }                                                                                                                                     \
+    static DynSmemAttr attr;                                                                                                              \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(dwx_fwd_kernel<S_, C_>), smem); e != hipSuccess) return (int)e;               \
     hipLaunchKernelGGL((dwx_fwd_kernel<S_, C_>), grid, dim3(256), smem, st, p);                                                           \
   } while (0)
 #define DX_FWD_S(C_)              \
@@ -915,18 +908,11 @@ extern "C" int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float
   p.dbg = cvh_tune_get(17);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
-  int dev = 0;
-  (void)hipGetDevice(&dev);
 #define DX_BWD(S_, C_)                                                                                                                    \
   do {                                                                                                                                    \
     const size_t smem = dwx_bwd_smem<S_, C_>();                                                                                           \
-    static unsigned attr_done = 0; /* one bit per device: the attribute is per device */                                                  \
-    if (smem > 64 * 1024 && !((attr_done >> (dev & 31)) & 1u)) {                                                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwx_bwd_kernel<S_, C_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)smem);                                                                                      \
-      if (e != hipSuccess) return (int)e;                                                                                                 \
-      attr_done |= 1u << (dev & 31);                                                                                                      \
-    }                                                                                                                                     \
+    static DynSmemAttr attr;                                                                                                              \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(dwx_bwd_kernel<S_, C_>), smem); e != hipSuccess) return (int)e;               \
     hipLaunchKernelGGL((dwx_bwd_kernel<S_, C_>), grid, dim3(256), smem, st, p);                                                           \
   } while (0)
 #define DX_BWD_S(C_)              \

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __rest
   }
 }
 
-long long g_cg_launches = 0, g_cg_bytes = 0;
+std::atomic<long long> g_cg_launches{0}, g_cg_bytes{0};  // updated from autograd worker threads
 void gemm_stream_counters(int reset, long long* out2);  // gemm_stream.hip
 extern "C" int cvh_stream_counters(int reset, long long* out) {
   if (out != nullptr) {
@@ -66,7 +66,8 @@ extern "C" int cvh_stream_counters(int reset, long long* out) {
   }
   if (reset) {
     gemm_stream_counters(1, nullptr);
-    g_cg_launches = g_cg_bytes = 0;
+    g_cg_launches = 0;
+    g_cg_bytes = 0;
   }
   return 0;
 }

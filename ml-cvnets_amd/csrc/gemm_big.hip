@@ -356,24 +356,14 @@ int launch_gemm_big(const ConvGemmParams& p0, hipStream_t st) {
     // the larger tile saves: CLIP's text tower at 19.7 k rows stays on the 128 x 128 kernel); knob 3: always the 128 x 128 kernel
     p.m_tiles = (p.M + 255) / 256;
     constexpr int smem = 2 * B2_STAGE;  // 128 KB
-    static unsigned attr_done = 0;  // one bit per device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_done >> (dev & 31)) & 1u)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      if (e != hipSuccess) return (int)e;
-      attr_done |= 1u << (dev & 31);
-    }
+    static DynSmemAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(gemm_nt256_kernel), smem); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(gemm_nt256_kernel, dim3(p.m_tiles * (p.N / 256)), dim3(512), smem, st, p);
   } else if (!ragged && cvh_tune_get(CVH_TUNE_BIG_GEMM) == 2 && p.M >= 8192) {  // 256 x 128 tiles, one 8-wave workgroup per CU
     p.m_tiles = (p.M + 255) / 256;
     constexpr int smem = 2 * (256 + 128) * BK * 2;  // 96 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt128_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    static DynSmemAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(gemm_nt128_kernel<4, false>), smem); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((gemm_nt128_kernel<4, false>), dim3(p.m_tiles * n_tiles), dim3(512), smem, st, p);
   } else {
     p.m_tiles = (p.M + 127) / 128;

@@ -301,10 +301,10 @@ bool gemm_stream_eligible(const ConvGemmParams& p) {
 
 // host-side tally of what went through this kernel family (bench.py: launches per step and their ALGORITHMIC bytes — every operand and
 // result tensor once: A, out, and the epilogue's aux / residual / saved pre-activation where present; weights and statistics neglected)
-static long long g_gs_launches = 0, g_gs_bytes = 0;
+static std::atomic<long long> g_gs_launches{0}, g_gs_bytes{0};  // updated from autograd worker threads
 void gemm_stream_counters(int reset, long long* out2) {  // C entry point: cvh_stream_counters (gemm.hip)
   if (out2 != nullptr) { out2[0] = g_gs_launches; out2[1] = g_gs_bytes; }
-  if (reset) g_gs_launches = g_gs_bytes = 0;
+  if (reset) { g_gs_launches = 0; g_gs_bytes = 0; }
 }
 
 template <int FW, int NKMAX, int EM> static int launch_gs(const ConvGemmParams& p, const GemmStreamGeom& g, size_t smem, hipStream_t st) {
@@ -314,12 +314,8 @@ template <int FW, int NKMAX, int EM> static int launch_gs(const ConvGemmParams& 
     g_gs_launches += 1;
     g_gs_bytes += (long long)p.M * ((long long)p.Ktot + (long long)p.N * (1 + extra)) * 2;
   }
-  static size_t attr = 0;  // one instantiation = one static
-  if (smem > 64 * 1024 && smem > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr = smem;
-  }
+  static DynSmemAttr attr;  // one instantiation = one static
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(g.gx * g.n_tiles), dim3(64 * GS_WAVES), smem, st, p, g);
   CVH_CHECK_LAUNCH();
   return 0;

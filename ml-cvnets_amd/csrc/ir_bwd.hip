@@ -224,13 +224,8 @@ extern "C" int cvh_ir_exp_bwd(int dtype, const void* g, const void* x, const voi
 #define IB_LAUNCH(HBK_, CB_)                                                                                                             \
   do {                                                                                                                                   \
     const size_t smem = ir_exp_smem<HBK_, CB_>();                                                                                        \
-    static bool attr = false;                                                                                                            \
-    if (smem > 64 * 1024 && !attr) {                                                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ir_exp_bwd_kernel<HBK_, CB_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)smem);                                                                                     \
-      if (e != hipSuccess) return (int)e;                                                                                                \
-      attr = true;                                                                                                                       \
-    }                                                                                                                                    \
+    static DynSmemAttr attr;                                                                                                             \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(ir_exp_bwd_kernel<HBK_, CB_>), smem); e != hipSuccess) return (int)e;  \
     hipLaunchKernelGGL((ir_exp_bwd_kernel<HBK_, CB_>), dim3(rows), dim3(IB_THREADS), smem, st, p);                                       \
   } while (0)
   if (hid == 64) IB_LAUNCH(4, 1);

@@ -200,13 +200,8 @@ extern "C" int cvh_ir_red_fwd(int dtype, const void* y2, const float* scale, con
 #define IF_LAUNCH(HBK_, NB_)                                                                                                             \
   do {                                                                                                                                   \
     const size_t smem = ir_red_fwd_smem<HBK_, NB_>();                                                                                    \
-    static bool attr = false;                                                                                                            \
-    if (smem > 64 * 1024 && !attr) {                                                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ir_red_fwd_kernel<HBK_, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)smem);                                                                                     \
-      if (e != hipSuccess) return (int)e;                                                                                                \
-      attr = true;                                                                                                                       \
-    }                                                                                                                                    \
+    static DynSmemAttr attr;                                                                                                             \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(ir_red_fwd_kernel<HBK_, NB_>), smem); e != hipSuccess) return (int)e;  \
     hipLaunchKernelGGL((ir_red_fwd_kernel<HBK_, NB_>), dim3(rows), dim3(IF_THREADS), smem, st, p);                                       \
   } while (0)
   if (hid == 64) IF_LAUNCH(4, 2);

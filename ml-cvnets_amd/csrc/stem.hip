@@ -314,12 +314,8 @@ extern "C" int cvh_stem_conv_dw(int in_dtype, const void* x_nchw, const void* dy
 #define STEM_DW(TI, NB)                                                                                                              \
   do {                                                                                                                               \
     const size_t smem = stem_dw_smem<NB>();                                                                                          \
-    static bool attr = false;                                                                                                        \
-    if (smem > 64 * 1024 && !attr) {                                                                                                 \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_dw_kernel<TI, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-      if (e != hipSuccess) return (int)e;                                                                                            \
-      attr = true;                                                                                                                   \
-    }                                                                                                                                \
+    static DynSmemAttr attr;                                                                                                         \
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(stem_dw_kernel<TI, NB>), smem); e != hipSuccess) return (int)e;    \
     hipLaunchKernelGGL((stem_dw_kernel<TI, NB>), grid, dim3(256), smem, st, p);                                                      \
   } while (0)
   if (in_dtype == CVH_DT_F32) {

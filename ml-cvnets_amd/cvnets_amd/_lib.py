@@ -169,9 +169,21 @@ def load():
     return lib
 
 
+_TRACE_CALLS = os.environ.get("CVH_TRACE_CALLS", "0") == "1"
+
+
 def call(name: str, *args) -> int:
     """Invoke a status-returning entry point; raise RuntimeError on any non-zero status."""
-    rc = getattr(load(), name)(*args)
+    if _TRACE_CALLS:  # debugging aid (CVH_TRACE_CALLS=1): name every launch before it runs and wait for it — an asynchronous GPU fault is
+        import sys     # then reported right after the line of the entry point that caused it
+        import torch
+        sys.stderr.write(f"[cvh] {name}\n")
+        sys.stderr.flush()
+        rc = getattr(load(), name)(*args)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc}" + (" (HIP out of memory)" if rc == 2 else ""))
     return rc

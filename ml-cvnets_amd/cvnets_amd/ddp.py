@@ -204,9 +204,7 @@ class DistributedDataParallel(nn.Module):
         tid = torch._C._current_graph_task_id()
         if self._callback_task != tid:
             if self._callback_task is not None:
-                for b in self.buckets:
-                    b.work = None
-                    b.pending = len(b.params)
+                self._discard_stale_task()
             self._callback_task = tid
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
         from . import ops
@@ -217,10 +215,28 @@ class DistributedDataParallel(nn.Module):
                 self._launch(b)
         return None
 
+    def _discard_stale_task(self):
+        """A new autograd graph task reached the hooks while `finish` of another one is still queued.  Normally that other backward raised
+        and its callback never ran: drop its bucket state.  A NESTED backward over DDP parameters (torch.utils.checkpoint with
+        use_reentrant=True, autograd.grad inside a custom backward) looks the same and is NOT supported — its gradients would be exchanged
+        per inner task: say so instead of reducing incomplete buckets silently (ops.checkpoint uses use_reentrant=False)."""
+        started = [b for b in self.buckets if b.work is not None or b.pending != len(b.params)]
+        if started:
+            import warnings
+            warnings.warn("cvnets_amd.ddp: a backward pass started while the gradient exchange of another one was unfinished "
+                          f"({len(started)} bucket(s) partly filled).  If the previous backward raised, this is the clean-up; nested / "
+                          "re-entrant backward passes over DDP parameters are not supported (use use_reentrant=False).")
+        for b in self.buckets:
+            b.work = None
+            b.pending = len(b.params)
+
     @contextlib.contextmanager
     def no_sync(self):
         """torch DDP's contract: backward passes inside the context accumulate locally, the first backward after it reduces the
-        accumulated gradients (gradient accumulation, engine/training_engine.py:221,289: `accum_freq` micro-steps per update)."""
+        accumulated gradients (gradient accumulation, engine/training_engine.py:221,289: `accum_freq` micro-steps per update).
+        Enter it OUTSIDE a backward pass (a backward already in progress has its exchange queued)."""
+        if torch._C._current_graph_task_id() >= 0:
+            raise RuntimeError("cvnets_amd.ddp.no_sync() must be entered outside a backward pass")
         prev = self.hooks_enabled
         self.hooks_enabled = False
         try:
@@ -235,9 +251,7 @@ class DistributedDataParallel(nn.Module):
         tid = torch._C._current_graph_task_id()
         if self._callback_task != tid:
             if self._callback_task is not None:  # the backward that queued `finish` died before it ran: start from a clean slate
-                for b in self.buckets:
-                    b.work = None
-                    b.pending = len(b.params)
+                self._discard_stale_task()
             self._callback_task = tid
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
         b = self._bucket_of[p]
@@ -351,7 +365,14 @@ class DistributedDataParallel(nn.Module):
         if self._buf_span is None:
             return False
         lo, hi = self.flat_buffers.data_ptr(), self.flat_buffers.data_ptr() + self.flat_buffers.numel() * self.flat_buffers.element_size()
-        return all(lo <= b.data_ptr() < hi for b in self._buf_span)
+        # every float buffer the module holds NOW (a re-registered or converted buffer is a different tensor object than the one captured)
+        n = 0
+        for b in self.module.buffers():
+            if b.dtype.is_floating_point:
+                n += 1
+                if not (lo <= b.data_ptr() < hi):
+                    return False
+        return n == len(self._buf_span)
 
     def forward(self, *args, **kwargs):
         if self.broadcast_buffers and self.active and self.training:

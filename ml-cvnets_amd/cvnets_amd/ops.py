@@ -178,6 +178,13 @@ def dropout_seed(device) -> torch.Tensor:
     return snap if snap is not None else _seed_state(device)
 
 
+def release_capture_state() -> None:
+    """Drop the module-level references to tensors that were allocated INSIDE a hipGraph capture (the per-forward dropout seed snapshot lives in
+    the capturing graph's private memory pool).  Call it before destroying such a graph: a tensor that outlives the pool it was allocated
+    from keeps a block of a dead pool alive (tests that capture and discard several graphs in one process)."""
+    _seed_snap.clear()
+
+
 def advance_dropout_seed(device) -> None:
     """Called once at the start of every training forward (captured into the step's hipGraph, so replays draw
     fresh masks): advances the generator state and snapshots it for this forward."""
@@ -190,7 +197,7 @@ def next_stream_id() -> int:
     return next(_stream_ids) & 0xFFFFFFFF
 
 
-# Debug export of the dropout draws (tests only: tests/test_dropout_step_gpu.py feeds the oracle the masks the kernels drew).
+# Debug export of the dropout draws (tests only: tests/test_zz_dropout_step_gpu.py feeds the oracle the masks the kernels drew).
 _dropout_trace = None  # None, or a list that every dropout site of a forward appends (kind, stream id, p, shape of the masked tensor) to
 
 
@@ -432,7 +439,6 @@ _side_streams = {}
 # id of the autograd graph task (one per backward call) whose end-of-backward callback is queued, or None.  Tied to the task id rather
 # than a bare flag: autograd DROPS queued callbacks when a backward raises (an OOM the engine skips, a kernel error), and a stale "already
 # queued" flag would make every later backward skip its join + deferred reductions — training on with missing gradients.
-_queued_task_id = None
 
 
 def _param_grad_stream(device):
@@ -449,43 +455,45 @@ def _param_grad_stream(device):
 
 
 def _join_param_grad_stream():
-    global _queued_task_id
-    _queued_task_id = None
     for dev, side in _side_streams.items():
         torch.cuda.current_stream(dev).wait_stream(side)
-    _flush_deferred_reductions()
 
 
 # Deferred reductions: "sum the partial rows" tails whose result only the optimizer reads (dW split partials, LayerNorm dgamma/dbeta,
 # bias gradients, depthwise dW) are queued during backward and executed by cvh_reduce_multi at the end of it — one launch per 48 tensors
 # instead of ~140 latency-bound launches per MobileViT-S step.  Only with in-place parameter gradients (the result must not be needed by
 # autograd) and inside a backward pass (the flush rides on the engine's end-of-backward callback).
+# The queue is kept PER autograd graph task: a nested / re-entrant backward (torch.utils.checkpoint(use_reentrant=True), autograd.grad
+# inside a custom backward) gets its own task id while the outer task is still alive — its callback flushes its own entries only.
 _DEFER_REDUCTIONS = os.environ.get("CVH_DEFER_REDUCE", "1") != "0"
-_pending_reductions = []
+_pending_by_task = {}  # graph-task id -> [(descriptor, partial buffer, destination)]; a key exists <=> that task's callback is queued
+
+
+def _end_of_backward(tid: int) -> None:
+    _join_param_grad_stream()
+    _flush_deferred_reductions(tid)
+    _pending_by_task.pop(tid, None)
 
 
 def _ensure_backward_callback() -> bool:
-    global _queued_task_id
     tid = torch._C._current_graph_task_id()
     if tid < 0:  # not inside a backward pass (direct Function.backward call in a test)
         return False
-    if tid != _queued_task_id:
-        if _queued_task_id is not None or _pending_reductions:
-            # the backward that queued them died before its callback ran: its partial buffers are gone, its gradients are void
-            _pending_reductions.clear()
-        torch.autograd.Variable._execution_engine.queue_callback(_join_param_grad_stream)
-        _queued_task_id = tid
+    if tid not in _pending_by_task:
+        _pending_by_task[tid] = []
+        torch.autograd.Variable._execution_engine.queue_callback(lambda tid=tid: _end_of_backward(tid))
     return True
 
 
 def finish_backward() -> None:
-    """Idempotent join of the parameter-gradient side stream + flush of the deferred reductions.  The end-of-backward callback normally
-    does both; the consumers of .grad (fused AdamW, DDP.allreduce_flat) call this first so that state can never leak across steps."""
+    """Idempotent join of the parameter-gradient side stream + drop of what a failed backward left queued.  The end-of-backward callback
+    normally joins and flushes; the consumers of .grad (fused AdamW, DDP.allreduce_flat) call this first so that state can never leak
+    across steps."""
     if torch._C._current_graph_task_id() >= 0:
-        return  # still inside the backward pass: its own callback will run
-    if _queued_task_id is not None or _pending_reductions:
-        # a callback that never ran (backward raised): the queued reductions belong to a void backward — drop them, but re-join the stream
-        _pending_reductions.clear()
+        return  # still inside a backward pass: its own callback will run
+    if _pending_by_task:
+        # callbacks that never ran (backward raised): the queued reductions belong to void backward passes — drop them, re-join the stream
+        _pending_by_task.clear()
         _join_param_grad_stream()
 
 
@@ -496,23 +504,26 @@ def defer_reduce(part, out, rows, row_stride, n_out, *, kind=0, N=0, Ktot=0, Cin
     desc = _lib.ReduceDesc(part.data_ptr() + 4 * int(part_offset), out.data_ptr(), int(row_stride), int(n_out), int(rows), int(kind), int(N), int(Ktot),
                            int(Cin), int(Cin_real), int(khw), float(scale), 1, 0)
     part.record_stream(torch.cuda.current_stream(part.device))
-    _pending_reductions.append((desc, part, out))
+    _pending_by_task[torch._C._current_graph_task_id()].append((desc, part, out))
     return True
 
 
 def flush_deferred_reductions() -> None:
-    """launch the reductions queued so far NOW (cvnets_amd.ddp: a gradient bucket is about to be all-reduced inside backward); later
-    reductions of the same backward queue up again and are flushed by the end-of-backward callback"""
-    _flush_deferred_reductions()
+    """launch the reductions the CURRENT backward pass queued so far NOW (cvnets_amd.ddp: a gradient bucket is about to be all-reduced inside
+    backward); later reductions of the same backward queue up again and are flushed by the end-of-backward callback"""
+    tid = torch._C._current_graph_task_id()
+    if tid >= 0:
+        _flush_deferred_reductions(tid)
 
 
-def _flush_deferred_reductions() -> None:
-    if not _pending_reductions:
+def _flush_deferred_reductions(tid: int) -> None:
+    pending = _pending_by_task.get(tid)
+    if not pending:
         return
     by_dev = {}
-    for item in _pending_reductions:
+    for item in pending:
         by_dev.setdefault(item[1].device, []).append(item)
-    _pending_reductions.clear()
+    pending.clear()
     for dev, items in by_dev.items():
         # cvh_reduce_multi adds into `out` without atomics, one workgroup set per descriptor: two descriptors with the SAME destination
         # (a shared weight, a module applied twice in one graph) must not share a launch — later duplicates go to later launches,

@@ -71,7 +71,10 @@ def test_failed_backward_does_not_poison_the_next_one():
         want_w = torch.ones(2048, 128, device="cuda").t() @ x
         assert torch.allclose(lin.weight.grad, want_w, rtol=1e-4, atol=1e-3 * float(want_w.abs().max()))
         assert torch.allclose(lin.bias.grad, torch.full((128,), 2048.0, device="cuda"))
-        assert not ops._pending_reductions and ops._queued_task_id is None
+        # the dead backward's entries are never flushed (they belong to ITS graph task); the consumers of .grad drop them
+        assert all(len(v) == 0 or k is not None for k, v in ops._pending_by_task.items())
+        ops.finish_backward()
+        assert not ops._pending_by_task
         ops.finish_backward()  # idempotent
     finally:
         ops.set_inplace_param_grads(False)

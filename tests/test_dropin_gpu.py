@@ -221,6 +221,7 @@ def test_captured_training_trajectory_matches_oracle(dtype):
     finally:
         ops.set_inplace_param_grads(False)
         cvnets_amd.set_compute_dtype(None)
+        ops.release_capture_state()  # the seed snapshot was allocated in the captured graph's memory pool, which dies with this test
 
 
 def test_reference_built_segmentation_model_runs_hip_kernels():

@@ -143,7 +143,7 @@ def load_keep_factors(gold):
 
 def test_oracle_with_dropout_factors_matches_reference_fixture():
     """mit.dropout = classifier_dropout = 0.1 (the shipped configuration): the oracle, fed the keep masks the reference drew, reproduces
-    the reference's training step — this pins WHERE the oracle applies dropout (tests/test_dropout_step_gpu.py relies on it)."""
+    the reference's training step — this pins WHERE the oracle applies dropout (tests/test_zz_dropout_step_gpu.py relies on it)."""
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     gold = np.load(os.path.join(GOLD, "mobilevit_xxs_dropout_64_b4.npz"))
     shapes = json.load(open(os.path.join(GOLD, "mobilevit_xx_small_keys.json")))

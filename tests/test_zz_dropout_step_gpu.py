@@ -208,3 +208,4 @@ def test_benchmarked_configuration_with_dropout_follows_the_oracle(dtype):
         ops.trace_dropout_sites(None)
         ops.set_inplace_param_grads(False)
         cvnets_amd.set_compute_dtype(None)
+        ops.release_capture_state()  # the seed snapshot was allocated in the captured graph's memory pool, which dies with this test

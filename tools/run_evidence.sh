@@ -15,3 +15,6 @@ cp $O/step_profile.json profiles/step_profile.json   # so that the bench line be
 (timeout 900 python bench.py 2>&1 | tail -1) > $O/bench.json; cut -c1-600 $O/bench.json
 cp $O/prof/bench_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 find $O -name "*counter_collection.csv" -size +8M -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; du -sh $O
+# extra lines of the round: the 128-image (8-GPU strong-scaling shard) step on one GPU, the engine-driven eager loop next to the replayed step
+(timeout 300 python bench.py --batch 128 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-probe 2>/dev/null | tail -1) > $O/bench_b128.json; cut -c1-200 $O/bench_b128.json
+(timeout 600 python tools/bench_engine.py --batch 128,1024 --graph-compare 2>/dev/null | grep "^{") > $O/bench_engine.jsonl; cut -c1-300 $O/bench_engine.jsonl

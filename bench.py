@@ -132,7 +132,17 @@ FAMILIES = {  # kernel families the library tallies (cvh_stream_counters): name 
                               "convolutions, BatchNorm-link expansion / projection GEMMs"),
     "conv_gemm_kernel": (1, "conv_gemm_kernel<T, NF, BK, FX, WP> (csrc/conv_gemm.hpp): the implicit-GEMM family — conv_1, operand-transform (BatchNorm-link) "
                             "projections, two-source expansion dX, K > 320 linears, classifier"),
+    # cvh_family_counters: the fused InvertedResidual kernels (indices 2 + family)
+    "dwx_fwd_kernel": (2, "dwx_fwd_kernel<S, CIN> (csrc/dwx.hip): expansion 1x1 + BatchNorm + SiLU + depthwise 3x3 of an InvertedResidual block, the 4x-wide "
+                          "expansion output recomputed from the narrow input; algorithmic bytes = x + y2"),
+    "dwx_bwd_kernel": (3, "dwx_bwd_kernel<S, CIN> (csrc/dwx.hip): backward of the same (depthwise dX and dW, SiLU', BatchNorm statistics) with y1 recomputed; "
+                          "algorithmic bytes = x + g2 + y2 + g1 (no halo)"),
+    "ir_pb_kernel": (4, "ir_pb_kernel<NA> (csrc/ir_pb.hip): projection backward of an InvertedResidual block from one pass over y2; algorithmic bytes = "
+                        "dout + y3 + y2 + g2"),
+    "ir_exp_bwd_kernel": (5, "ir_exp_bwd_kernel<HBK, CB> (csrc/ir_bwd.hip): expansion dX + raw dW from one pass over g1; algorithmic bytes = g1 + x + dx (+ residual)"),
+    "ir_red_fwd_kernel": (6, "ir_red_fwd_kernel<HBK, NB> (csrc/ir_fwd.hip): projection forward with BatchNorm + SiLU on load; algorithmic bytes = y2 + y3"),
 }
+N_FAMILY_COUNTERS = 5
 
 
 class _StreamGemmLog:
@@ -141,9 +151,10 @@ class _StreamGemmLog:
 
     def __init__(self):
         self.calls = []
+        self.dwx_bwd_calls = []
         self.launches = 0
         self.alg_bytes = 0
-        self.tallies = [0, 0, 0, 0]
+        self.tallies = [0] * (4 + 2 * N_FAMILY_COUNTERS)
 
     def __enter__(self):
         import ctypes
@@ -158,9 +169,13 @@ class _StreamGemmLog:
             return buf[0], buf[1]
 
         _lib.load().cvh_stream_counters(1, None)
+        for f in range(N_FAMILY_COUNTERS):
+            _lib.load().cvh_family_counters(f, 1, None)
         self._tally = tally
 
         def call(name, *a):
+            if name == "cvh_dwx_bwd":  # (dtype, x, w1, in_stats, act1, g_out, y_out, ca, cb, cc, wd, g_in, stats, dw, B, H, W, Ho, Wo, Cin, hid, stride, st)
+                self.dwx_bwd_calls.append(tuple(a[14:22]))
             if name not in ("cvh_conv_gemm", "cvh_pw_gemm_bn"):
                 return self._orig(name, *a)
             n0, _ = tally()
@@ -179,8 +194,48 @@ class _StreamGemmLog:
 
     def __exit__(self, *exc):
         self._lib.call = self._orig
+        import ctypes
         self.launches, self.alg_bytes = self._tally()
         self.tallies = list(self._buf)
+        b2 = (ctypes.c_longlong * 2)()
+        for f in range(N_FAMILY_COUNTERS):
+            self._lib.load().cvh_family_counters(f, 0, b2)
+            self.tallies += [b2[0], b2[1]]
+
+
+def dwx_bwd_probe(log):
+    """isolated re-timing of the step's dwx_bwd_kernel launches (synthetic operands of the recorded geometries), HIP events on the launch
+    stream; returns (total ms per step's worth of launches, launches)"""
+    from cvnets_amd import _lib
+    dev = torch.device("cuda")
+    st = torch.cuda.current_stream()
+    total_ms, n = 0.0, 0
+    for (B, H, W, Ho, Wo, Cin, hid, stride) in log.dwx_bwd_calls:
+        x = torch.randn(B * H * W, Cin, device=dev).bfloat16()
+        w1 = (torch.randn(hid, Cin, device=dev) * Cin ** -0.5).bfloat16()
+        wd = (torch.randn(9, hid, device=dev) * 0.4).bfloat16()
+        stats = torch.stack([torch.zeros(hid, device=dev), torch.ones(hid, device=dev), torch.ones(hid, device=dev), torch.zeros(hid, device=dev)]).contiguous()
+        g2 = torch.randn(B * Ho * Wo, hid, device=dev).bfloat16()
+        y2 = torch.randn(B * Ho * Wo, hid, device=dev).bfloat16()
+        g1 = torch.empty(B * H * W, hid, device=dev, dtype=torch.bfloat16)
+        ca, cb, cc = torch.ones(hid, device=dev), torch.full((hid,), 0.1, device=dev), torch.zeros(hid, device=dev)
+        R = _lib.query("cvh_dwx_rows", B, Ho, Wo, hid, stride)
+        part, dwp = torch.empty(R * 2 * hid, device=dev), torch.empty(R * hid * 9, device=dev)
+
+        def go():
+            _lib.call("cvh_dwx_bwd", 1, x.data_ptr(), w1.data_ptr(), stats.data_ptr(), 1, g2.data_ptr(), y2.data_ptr(), ca.data_ptr(), cb.data_ptr(),
+                      cc.data_ptr(), wd.data_ptr(), g1.data_ptr(), part.data_ptr(), dwp.data_ptr(), B, H, W, Ho, Wo, Cin, hid, stride, st.cuda_stream)
+
+        go()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(3):
+            go()
+        e1.record(st)
+        torch.cuda.synchronize()
+        total_ms += e0.elapsed_time(e1) / 3
+        n += 1
+    return total_ms, n
 
 
 def stream_gemm_probe(log):
@@ -438,8 +493,9 @@ def run(args):
         fi, fdesc = FAMILIES[dom]
         n_l, n_b = dw_log.tallies[2 * fi], dw_log.tallies[2 * fi + 1]
         dk = {"kernel": fdesc, "family": dom, "launches_per_step": int(n_l), "algorithmic_bytes": int(n_b / max(n_l, 1)),
-              "algorithmic_bytes_note": "per launch, averaged over the step's launches: input tensor(s) + out + every [M][N] epilogue operand, tallied by the "
-                                        "library during one eager step (cvh_stream_counters)"}
+              "algorithmic_bytes_note": "per launch, averaged over the step's launches: every operand and result tensor of the launch once (input tensor(s) + "
+                                        "out + every [M][N] epilogue operand; no halo re-reads), tallied by the library during one eager step "
+                                        "(cvh_stream_counters / cvh_family_counters)"}
         if prof is not None and not stale:
             fam = {f["family"]: f for f in prof["families"]}
             f = fam.get(dom)
@@ -456,15 +512,22 @@ def run(args):
                                for k in list(fam)[:4] if k != dom}
         if not args.no_kernel_probe:
             try:
-                iso_ms, n_iso = stream_gemm_probe(dw_log)
-                iso = {"kernel": "gemm_stream_kernel", "launches": n_iso, "total_ms_per_step": round(iso_ms, 3), "avg_ms": round(iso_ms / max(n_iso, 1), 5),
-                       "achieved_GBps": round(dw_log.alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
-                       "what": "the step's gemm_stream_kernel launches re-issued back to back on synthetic operands, HIP events on the launch stream"}
+                if dom == "dwx_bwd_kernel":
+                    iso_ms, n_iso = dwx_bwd_probe(dw_log)
+                    iso_bytes = n_b
+                else:
+                    iso_ms, n_iso = stream_gemm_probe(dw_log)
+                    iso_bytes = dw_log.alg_bytes
+                iso_name = dom if dom == "dwx_bwd_kernel" else "gemm_stream_kernel"
+                iso = {"kernel": iso_name, "launches": n_iso, "total_ms_per_step": round(iso_ms, 3), "avg_ms": round(iso_ms / max(n_iso, 1), 5),
+                       "achieved_GBps": round(iso_bytes / (iso_ms * 1e-3) / 1e9, 1),
+                       "what": f"the step's {iso_name} launches re-issued back to back on synthetic operands, HIP events on the launch stream"}
                 dk["isolated_probe"] = iso
-                dk["isolated_avg_ms"], dk["isolated_achieved_GBps"] = iso["avg_ms"], iso["achieved_GBps"]
-                if "avg_ms" not in dk:  # no valid profile: the live numbers are all there is
-                    dk.update({"avg_ms": dk["isolated_avg_ms"], "avg_ms_source": "isolated HIP-event probe (no valid profiles/step_profile.json for this source tree)",
-                               "achieved_GBps": dk["isolated_achieved_GBps"], "frac": round(dk["isolated_achieved_GBps"] * 1e9 / HBM_PEAK, 4)})
+                if iso_name == dom:  # (a live probe of another family than the one the profile ranks first stays apart)
+                    dk["isolated_avg_ms"], dk["isolated_achieved_GBps"] = iso["avg_ms"], iso["achieved_GBps"]
+                    if "avg_ms" not in dk:  # no valid profile: the live numbers are all there is
+                        dk.update({"avg_ms": dk["isolated_avg_ms"], "avg_ms_source": "isolated HIP-event probe (no valid profiles/step_profile.json for this source tree)",
+                                   "achieved_GBps": dk["isolated_achieved_GBps"], "frac": round(dk["isolated_achieved_GBps"] * 1e9 / HBM_PEAK, 4)})
             except Exception as e:  # pragma: no cover
                 dk["probe_error"] = str(e)[:200]
         roofline["dominant_kernel"] = dk

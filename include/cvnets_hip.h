@@ -85,6 +85,10 @@ int cvh_stem_conv_dw(int in_dtype, const void* x_nchw, const void* dy_bf16, floa
  * epilogue operand) of the two GEMM kernel families: out[0..1] = gemm_stream_kernel, out[2..3] = conv_gemm_kernel; out = long long[4];
  * reset != 0 clears the tallies */
 int cvh_stream_counters(int reset, long long* out);
+/* the same for the kernel families of the fused InvertedResidual block: family 0 = dwx_fwd_kernel (x + y2), 1 = dwx_bwd_kernel (x + g2 + y2 +
+ * g1), 2 = ir_pb_kernel (dy (+ y3) + y2 + g2), 3 = ir_exp_bwd_kernel (g1 + x + dx), 4 = ir_red_fwd_kernel (y2 + y3); out = long long[2]
+ * (launches, algorithmic bytes: every operand and result tensor once, no halo); -2 for an unknown family */
+int cvh_family_counters(int family, int reset, long long* out);
 /* scratch floats cvh_gemm_dw / cvh_gemm_dw_bias want for a convolution geometry (a multiple of N * KH*KW*(C1+C2): the number of partial rows
  * the chosen kernel writes).  Equals cvh_gemm_dw_scratch_elems(M, N, K) except for the 3x3 stride-1 convs of the MobileViT blocks. */
 long long cvh_gemm_dw_scratch_elems_conv(int dtype, int B, int H, int W, int Ho, int Wo, int C1, int C2, int KH, int KW, int stride, int pad,

@@ -386,6 +386,9 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_MAX 24
 int cvh_tune_get(int key);
 
+// host-side tally of a kernel family's launches and algorithmic bytes (cvh_family_counters; defined in gemm.hip)
+void cvh_family_tally(int family, long long bytes);
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: cache of the size already granted, one slot per device
 // (a process that touches a second GPU must set it there too).  One static instance per kernel instantiation.
 struct DynSmemAttr {

@@ -861,6 +861,7 @@ extern "C" int cvh_dwx_fwd(int dtype, const void* x, const void* w1, const float
   const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
   p.ntiles = B * p.tiles_h * p.tiles_w;
   p.dbg = cvh_tune_get(17);
+  cvh_family_tally(0, ((long long)B * H * W * Cin + (long long)B * Ho * Wo * hid) * 2);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
 #define DX_FWD(S_, C_)                                                                                                                    \
@@ -906,6 +907,7 @@ extern "C" int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float
   const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
   p.ntiles = B * p.tiles_h * p.tiles_w;
   p.dbg = cvh_tune_get(17);
+  cvh_family_tally(1, ((long long)B * H * W * (Cin + hid) + (long long)B * Ho * Wo * hid * (y_out != nullptr ? 2 : 1)) * 2);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
 #define DX_BWD(S_, C_)                                                                                                                    \

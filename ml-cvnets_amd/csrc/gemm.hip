@@ -57,6 +57,18 @@ __global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __rest
 }
 
 std::atomic<long long> g_cg_launches{0}, g_cg_bytes{0};  // updated from autograd worker threads
+static std::atomic<long long> g_fam[5][2];
+void cvh_family_tally(int family, long long bytes) {
+  if (family < 0 || family >= 5) return;
+  g_fam[family][0] += 1;
+  g_fam[family][1] += bytes;
+}
+extern "C" int cvh_family_counters(int family, int reset, long long* out) {
+  if (family < 0 || family >= 5) return -2;
+  if (out != nullptr) { out[0] = g_fam[family][0]; out[1] = g_fam[family][1]; }
+  if (reset) { g_fam[family][0] = 0; g_fam[family][1] = 0; }
+  return 0;
+}
 void gemm_stream_counters(int reset, long long* out2);  // gemm_stream.hip
 extern "C" int cvh_stream_counters(int reset, long long* out) {
   if (out != nullptr) {

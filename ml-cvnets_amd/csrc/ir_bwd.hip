@@ -220,6 +220,7 @@ extern "C" int cvh_ir_exp_bwd(int dtype, const void* g, const void* x, const voi
   p.g = reinterpret_cast<const bf16_t*>(g); p.x = reinterpret_cast<const bf16_t*>(x); p.wcat = reinterpret_cast<const bf16_t*>(wcat);
   p.bias = bias; p.res = reinterpret_cast<const bf16_t*>(residual); p.dx = reinterpret_cast<bf16_t*>(dx); p.ppart = p_part;
   p.M = (int)M; p.hid = hid; p.Cin = Cin; p.ntiles = (int)((M + IB_TM - 1) / IB_TM);
+  cvh_family_tally(3, (long long)M * (hid + Cin * (residual != nullptr ? 3 : 2)) * 2);
   hipStream_t st = (hipStream_t)stream;
 #define IB_LAUNCH(HBK_, CB_)                                                                                                             \
   do {                                                                                                                                   \

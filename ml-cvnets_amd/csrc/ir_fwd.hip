@@ -196,6 +196,7 @@ extern "C" int cvh_ir_red_fwd(int dtype, const void* y2, const float* scale, con
   IrRedFwdParams p;
   p.y2 = reinterpret_cast<const bf16_t*>(y2); p.scale = scale; p.shift = shift; p.w = reinterpret_cast<const bf16_t*>(wgt);
   p.out = reinterpret_cast<bf16_t*>(out); p.stats_part = stats_part; p.act = act; p.M = (int)M; p.ntiles = (int)((M + IF_TM - 1) / IF_TM);
+  cvh_family_tally(4, (long long)M * (hid + N) * 2);
   hipStream_t st = (hipStream_t)stream;
 #define IF_LAUNCH(HBK_, NB_)                                                                                                             \
   do {                                                                                                                                   \

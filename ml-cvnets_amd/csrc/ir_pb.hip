@@ -269,6 +269,7 @@ extern "C" int cvh_ir_pb(int dtype, const void* dy, const void* y3, const float*
   p.R = ir_pb_plan(M, hid, &p.chunks, &p.ntiles);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(p.R * p.chunks);
+  cvh_family_tally(2, ((long long)M * Cout * (y3 != nullptr ? 2 : 1) + 2LL * M * hid) * 2);
 #define IR_PB(NA_) hipLaunchKernelGGL((ir_pb_kernel<NA_>), grid, dim3(256), ir_pb_smem<NA_>(), st, p)
   switch (Cout / 16) {
     case 2: IR_PB(2); break;

@@ -32,6 +32,7 @@ SIGNATURES = {
     "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
     "cvh_conv_gemm_grid_rows": [I, I],
     "cvh_stream_counters": [I, P],  # out = long long[4]
+    "cvh_family_counters": [I, I, P],  # out = long long[2]
     "cvh_stem_rows": [I, I, I, I],
     "cvh_ir_exp_bwd_rows": [L, I, I],
     "cvh_dwx_rows": [I, I, I, I, I],

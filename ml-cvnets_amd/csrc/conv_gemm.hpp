@@ -415,14 +415,8 @@ static int launch_conv_gemm(const ConvGemmParams& p0, hipStream_t st) {
   constexpr int MAIN_ELEMS = TILE_ELEMS + STAGE_ELEMS;
   size_t smem = (size_t)MAIN_ELEMS * sizeof(T) + (size_t)(2 + (FX ? 4 : 0)) * BN * sizeof(float);
   auto kern = conv_gemm_kernel<T, NF, BK, FX, WP>;
-  if (smem > 64 * 1024) {
-    static bool attr_set = false;  // one instantiation = one static
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-  }
+  static DynSmemAttr attr;  // one instantiation = one static
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), smem); e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   CVH_CHECK_LAUNCH();
   return 0;

@@ -1,6 +1,6 @@
 """Micro-benchmark of the dwx kernels (csrc/dwx.hip) at the InvertedResidual shapes of the 1024-image MobileViT-S step, next to the kernels
 they replace (expansion GEMM + cvh_dwconv_bn_fwd / cvh_dwconv_bn_bwd): us per launch and GB/s of algorithmic traffic.
-    python tools/bench_dwx.py [--batch 1024] [--reps 5] [--only new|old]"""
+    python tools/bench_dwx.py [--batch 1024] [--reps 5] [--only new|old] [--shape i] [--dbg bits]"""
 import argparse
 import os
 import sys
@@ -34,14 +34,10 @@ def main():
     ap.add_argument("--only", default="both")
     ap.add_argument("--dbg", type=int, default=0, help="CVH_TUNE key 17: phase-skip bits of the dwx kernels (timing experiments; results wrong)")
     ap.add_argument("--shape", type=int, default=-1, help="index into SHAPES (-1: all)")
-    ap.add_argument("--narrow", type=int, default=0, help="CVH_TUNE key 19 = 1: 8-byte stores straight from the accumulators")
-    ap.add_argument("--stagger", type=int, default=0, help="CVH_TUNE key 18: start-up de-phasing of the dwx workgroups (x ~1k cycles)")
     a = ap.parse_args()
     B = a.batch
     st = torch.cuda.current_stream().cuda_stream
     _lib.call("cvh_set_tuning", 17, a.dbg)
-    _lib.call("cvh_set_tuning", 18, a.stagger)
-    _lib.call("cvh_set_tuning", 19, a.narrow)
     for (H, W, Cin, hid, s) in (SHAPES if a.shape < 0 else [SHAPES[a.shape]]):
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         g = torch.Generator(device=DEV).manual_seed(1)

@@ -598,8 +598,11 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
     if (tix + t_step < p.ntiles) load_tile(tix + t_step);  // next tile's operands, in flight under this tile's arithmetic
 
     // ---- per 16-pixel block: y1 -> z, act', xhat;  dz = stencil^T(dy);  g1 = dz * act' ----
-    // (not unrolled: eight blocks' worth of hoisted operand reads would push the persistent accumulators into scratch)
-#pragma unroll 1
+    // Unrolled by four: two waves per SIMD leave the scheduler little else to overlap a block's MFMAs and LDS reads with the previous block's
+    // epilogue (stride-2 launches -6 ... -13 %, stride 1 -1 ... -5 % against the rolled loop).  Stride 2 with Cin <= 64 unrolls all eight
+    // blocks: the parity class of a block becomes a compile-time constant and the dispatch on it disappears (another -6 ... -11 %); elsewhere
+    // eight blocks' worth of hoisted operand reads push the persistent accumulators into scratch.
+#pragma unroll (S == 2 && CIN <= 64 ? 8 : 4)
     for (int pb = 0; pb < 8; ++pb) {
       // tile coordinates of this lane's pixel
       int r, c;

@@ -601,23 +601,33 @@ class MultiHeadAttention(nn.Module):
                 attn_mask: Optional[Tensor] = None, *args, **kwargs) -> Tensor:
         if x_kv is not None:
             raise NotImplementedError("cross-attention is not on the HIP hot path")
-        if kwargs.get("use_pytorch_mha", False) or self.coreml_compatible:
-            raise NotImplementedError("forward_pytorch / forward_tracing variants are not on the HIP hot path")
+        if self.coreml_compatible:
+            raise NotImplementedError("the forward_tracing variant is not on the HIP hot path")
+        seq_first = bool(kwargs.get("use_pytorch_mha", False))
+        if seq_first:
+            # forward_pytorch (multi_head_attention.py:241-273): F.multi_head_attention_forward on the SAME weights, input [S, B, C]; the
+            # kernels gather batch-first sequences, so the tensor is transposed on the way in and out (plumbing copies: not a path any shipped
+            # model takes)
+            x_q = x_q.transpose(0, 1)
         b, s, c = x_q.shape
         causal = False
         if attn_mask is not None:
-            causal = _mask_is_causal(attn_mask, b, s)
+            causal = _mask_is_causal(attn_mask, b, s, allow_2d=seq_first)
         x2 = x_q.reshape(b * s, c)
         if x2.dtype != ops.compute_dtype():
             x2 = x2.to(ops.compute_dtype())
         y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask)
-        return y.view(b, s, -1)
+        y = y.view(b, s, -1)
+        return y.transpose(0, 1) if seq_first else y
 
 
-def _mask_is_causal(attn_mask: Tensor, b: int, s: int) -> bool:
+def _mask_is_causal(attn_mask: Tensor, b: int, s: int, allow_2d: bool = False) -> bool:
     """The only additive mask on the reference's path is the CLIP text tower's causal mask
-    (cvnets/text_encoders/transformer.py:343-352); it is generated in-kernel.  Anything else is rejected."""
-    if list(attn_mask.shape) != [b, s, s]:
+    (cvnets/text_encoders/transformer.py:343-352); it is generated in-kernel.  Anything else is rejected.  (`allow_2d`: the [S, S] form
+    F.multi_head_attention_forward takes.)"""
+    if allow_2d and list(attn_mask.shape) == [s, s]:
+        attn_mask = attn_mask[None]
+    elif list(attn_mask.shape) != [b, s, s]:
         raise AssertionError(f"Shape of attention mask should be [{b}, {s}, {s}]. Got: {attn_mask.shape}")
     m = attn_mask[0]
     ref = torch.full((s, s), float("-inf"), device=m.device, dtype=m.dtype).triu(1)

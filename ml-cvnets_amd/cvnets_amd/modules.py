@@ -161,8 +161,7 @@ class TransformerEncoder(nn.Module):
             raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
         p1 = drop1.p if self.training else 0.0
         p2 = drop2.p if self.training else 0.0
-        if drop_ffn.p > 0.0 and self.training:
-            raise NotImplementedError("ffn_dropout > 0 is not fused (reference YAMLs use 0.0)")
+        pf = drop_ffn.p if self.training else 0.0  # ffn_dropout (transformer.py:92; 0.0 in every shipped YAML): un-fused — a standalone pass over the hidden tensor
         sd = self.drop_path.p if (self.training and isinstance(self.drop_path, StochasticDepth)) else 0.0
         if sd > 0.0:
             # x = x + StochasticDepth(Dropout(branch(LN(x)))): one Bernoulli draw per sample scales the whole branch; the residual add rides in
@@ -170,7 +169,8 @@ class TransformerEncoder(nn.Module):
             y = ops.layer_norm_tokens(x, ln1, seqmap)
             x = ops.drop_path(mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1), x, sd, True, seqmap)
             y = ops.layer_norm_tokens(x, ln2, seqmap)
-            h = ops.linear(ops.linear(y, fc1.weight, fc1.bias, act=act_code(act)), fc2.weight, fc2.bias, drop_p=p2)
+            h = ops.dropout(ops.linear(y, fc1.weight, fc1.bias, act=act_code(act)), pf, pf > 0.0)
+            h = ops.linear(h, fc2.weight, fc2.bias, drop_p=p2)
             return ops.drop_path(h, x, sd, True, seqmap)
         # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue; the fork x -> (x, LN(x)) is one autograd
         # node, so the two gradients of x meet inside the LayerNorm backward kernel
@@ -179,6 +179,9 @@ class TransformerEncoder(nn.Module):
         # x = x + Dropout(W2 act(W1 LN(x)))
         x, y = ops.layer_norm_fork(x, ln2, seqmap)
         a = act_code(act)
+        if pf > 0.0:
+            h = ops.dropout(ops.linear(y, fc1.weight, fc1.bias, act=a), pf, True)
+            return ops.linear(h, fc2.weight, fc2.bias, drop_p=p2, residual=x)
         if not _FUSED_FFN_BWD or fc1.out_features >= 1024:
             # transformer-sized FFNs (ViT-B: 3072 hidden): measured -4.5 % with the fusion — the erf/exp epilogue serialises behind
             # the MFMA-bound large-tile GEMM, while the separate elementwise pass runs at HBM speed; MobileViT-sized FFNs gain ~1 %

@@ -1,0 +1,94 @@
+"""Two variants of the reference layers that no shipped YAML uses but the layer contract lists:
+  * MultiHeadAttention(..., use_pytorch_mha=True) — forward_pytorch (cvnets/layers/multi_head_attention.py:241-273): sequence-first input through
+    F.multi_head_attention_forward on the same weights; checked against exactly that torch call (fp32), with a key-padding mask and the
+    causal [S, S] additive mask;
+  * TransformerEncoder(ffn_dropout > 0) (cvnets/modules/transformer.py:92): checked against the torch formulas fed the mask the kernel drew.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("masked", ["none", "key_padding", "causal"])
+def test_use_pytorch_mha_sequence_first(masked):
+    import cvnets_amd
+    torch.manual_seed(3)
+    S, B, C, H = 19, 3, 64, 4
+    m = cvnets_amd.MultiHeadAttention(C, H).to(DEV).train()
+    x = torch.randn(S, B, C, device=DEV, requires_grad=True)
+    kpm = None
+    am = None
+    if masked == "key_padding":
+        kpm = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        kpm[0, 15:] = True
+        kpm[2, 7:] = True
+    if masked == "causal":
+        am = torch.full((S, S), float("-inf"), device=DEV).triu(1)
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        y = m(x, key_padding_mask=kpm, attn_mask=am, use_pytorch_mha=True)
+        go = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, [x], go)
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    xr = x.detach().clone().requires_grad_(True)
+    w = m.qkv_proj.weight.detach()
+    ref, _ = F.multi_head_attention_forward(
+        query=xr, key=xr, value=xr, embed_dim_to_check=C, num_heads=H, in_proj_weight=torch.empty([0]), in_proj_bias=m.qkv_proj.bias.detach(),
+        bias_k=None, bias_v=None, add_zero_attn=False, dropout_p=0.0, out_proj_weight=m.out_proj.weight.detach(),
+        out_proj_bias=m.out_proj.bias.detach(), training=True, key_padding_mask=kpm, need_weights=False, attn_mask=am,
+        use_separate_proj_weight=True, q_proj_weight=w[:C], k_proj_weight=w[C:2 * C], v_proj_weight=w[2 * C:])
+    (rx,) = torch.autograd.grad(ref, [xr], go)
+    assert y.shape == ref.shape == (S, B, C)
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 2e-4
+    assert float((gx.float() - rx).abs().max() / rx.abs().max()) < 2e-3
+
+
+def test_transformer_encoder_with_ffn_dropout():
+    import cvnets_amd
+    from cvnets_amd import ops
+    from cvnets_amd.layers import default_opts
+    torch.manual_seed(5)
+    B, S, C, FFN, p = 4, 32, 64, 128, 0.3
+    enc = cvnets_amd.modules.TransformerEncoder(default_opts(), embed_dim=C, ffn_latent_dim=FFN, num_heads=4, attn_dropout=0.0, dropout=0.0,
+                                               ffn_dropout=p).to(DEV).train()
+    x = torch.randn(B, S, C, device=DEV, requires_grad=True)
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        sites = []
+        ops.trace_dropout_sites(sites)
+        y = enc(x)
+        ops.trace_dropout_sites(None)
+        seed = ops.dropout_seed(x.device).clone()
+        go = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, [x], go)
+        assert len(sites) == 1 and sites[0][0] == "dropout" and sites[0][3] == (B * S, FFN), sites
+        mask = ops.dropout_keep_scale(seed, sites[0][1], sites[0][3], p).view(B, S, FFN)
+        assert 0.2 < float((mask == 0).float().mean()) < 0.4
+        enc.eval()
+        y_eval = enc(x.detach())  # eval: no dropout at all
+    finally:
+        ops.trace_dropout_sites(None)
+        cvnets_amd.set_compute_dtype(None)
+    ln1, mha = enc.pre_norm_mha[0], enc.pre_norm_mha[1]
+    ln2, fc1, fc2 = enc.pre_norm_ffn[0], enc.pre_norm_ffn[1], enc.pre_norm_ffn[4]
+
+    def ref(xr, mk):
+        t = F.layer_norm(xr, (C,), ln1.weight, ln1.bias, ln1.eps)
+        qkv = F.linear(t, mha.qkv_proj.weight, mha.qkv_proj.bias).view(B, S, 3, 4, C // 4).permute(2, 0, 3, 1, 4)
+        a = torch.softmax((qkv[0] * (C // 4) ** -0.5) @ qkv[1].transpose(-1, -2), dim=-1) @ qkv[2]
+        x1 = xr + F.linear(a.transpose(1, 2).reshape(B, S, C), mha.out_proj.weight, mha.out_proj.bias)
+        h = F.silu(F.linear(F.layer_norm(x1, (C,), ln2.weight, ln2.bias, ln2.eps), fc1.weight, fc1.bias))
+        if mk is not None:
+            h = h * mk
+        return x1 + F.linear(h, fc2.weight, fc2.bias)
+
+    xr = x.detach().clone().requires_grad_(True)
+    r = ref(xr, mask)
+    (rx,) = torch.autograd.grad(r, [xr], go)
+    assert float((y.float() - r).abs().max() / r.abs().max()) < 2e-4
+    assert float((gx.float() - rx).abs().max() / rx.abs().max()) < 2e-3
+    assert float((y_eval.float() - ref(x.detach(), None)).abs().max() / r.abs().max()) < 2e-4

@@ -280,7 +280,8 @@ class DistributedDataParallel(nn.Module):
     def finish(self):
         """end of backward: launch whatever was not launched, wait, average."""
         from . import ops
-        ops.flush_deferred_reductions()  # whichever end-of-backward callback runs first: no partial sum may still be queued
+        # whichever end-of-backward callback runs first: no partial sum of THIS backward may still be queued
+        ops.flush_deferred_reductions(self._callback_task)
         self.finish_count += 1
         late = 0
         for b in self.buckets:

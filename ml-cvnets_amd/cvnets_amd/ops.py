@@ -508,10 +508,12 @@ def defer_reduce(part, out, rows, row_stride, n_out, *, kind=0, N=0, Ktot=0, Cin
     return True
 
 
-def flush_deferred_reductions() -> None:
-    """launch the reductions the CURRENT backward pass queued so far NOW (cvnets_amd.ddp: a gradient bucket is about to be all-reduced inside
-    backward); later reductions of the same backward queue up again and are flushed by the end-of-backward callback"""
-    tid = torch._C._current_graph_task_id()
+def flush_deferred_reductions(task: Optional[int] = None) -> None:
+    """launch the reductions a backward pass queued so far NOW (cvnets_amd.ddp: a gradient bucket is about to be all-reduced); later
+    reductions of the same backward queue up again and are flushed by the end-of-backward callback.  `task` = the autograd graph-task id
+    whose queue is meant (default: the one that is running; an end-of-backward callback passes the id it was registered under, since
+    the order of the engine's final callbacks is the order in which they were queued, not ours to choose)"""
+    tid = torch._C._current_graph_task_id() if task is None else task
     if tid >= 0:
         _flush_deferred_reductions(tid)
 

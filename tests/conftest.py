@@ -36,3 +36,16 @@ if os.environ.get("CVH_TEST_NAN_FILL"):
 
     torch.use_deterministic_algorithms(True, warn_only=True)
     torch.utils.deterministic.fill_uninitialized_memory = True
+
+
+@pytest.fixture(autouse=True)
+def _drop_capture_owned_caches(request):
+    """After every GPU test: drop the module-level caches that can hold tensors allocated INSIDE a hipGraph capture (packed weight images
+    re-packed during a captured step, the per-forward dropout-seed snapshot).  A test that captures a graph and lets it die would otherwise
+    leave tensors of a dead private memory pool referenced from module globals for the rest of the process ("Open")."""
+    yield
+    if "gpu" in request.keywords:
+        ops = sys.modules.get("cvnets_amd.ops")
+        if ops is not None:
+            ops._PACKED.clear()
+            ops._seed_snap.clear()

@@ -64,3 +64,72 @@ def test_conv_dw_scratch_query_switches_kernels_by_geometry():
     assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, B, H, H, H, H, 96, 0, 3, 3, 1, 1, 1, 96, 1) == generic       # bias folded: im2col kernel
     assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, B, H, H, H, H, 96, 0, 3, 3, 1, 1, 1, 64, 0) == _lib.query("cvh_gemm_dw_scratch_elems", M, 64, 864)
     assert _lib.query("cvh_gemm_dw_scratch_elems_conv", 1, M, 1, 1, 1, 1, 144, 0, 1, 1, 1, 0, 1, 432, 0) == _lib.query("cvh_gemm_dw_scratch_elems", M, 432, 144)
+
+
+def test_round4_size_queries_and_eligibility():
+    """cvh_ir_pb_rows (one-pass projection backward) and cvh_dwx_rows (y1-recomputing depthwise kernels): host-only planners — > 0 exactly for the
+    shapes the kernels are instantiated for; fused._dwx_eligible mirrors the C side's refusals."""
+    from cvnets_amd import _lib, fused, ops
+    M = 1024 * 64 * 64
+    assert _lib.query("cvh_ir_pb_rows", M, 256, 64) == 768 // 4          # ~3 workgroups per CU, split over the 4 channel chunks
+    assert _lib.query("cvh_ir_pb_rows", 1024 * 128 * 128, 64, 32) == 768
+    assert _lib.query("cvh_ir_pb_rows", 1024 * 8 * 8, 512, 160) == 768 // 8
+    assert _lib.query("cvh_ir_pb_rows", 5000, 512, 160) == (5000 + 63) // 64     # fewer tiles than workgroup slots: one tile each
+    for M_, hid, cout in ((1000, 256, 64), (M, 72, 32), (M, 256, 48), (M, 256, 192), (M, 256, 24)):   # tiny, hid % 64, Cout % 32, > 160, < 32
+        assert _lib.query("cvh_ir_pb_rows", M_, hid, cout) == 0
+    # dwx: 2048 / chunks workgroups (<= 1024, >= 32), never more than there are tiles
+    assert _lib.query("cvh_dwx_rows", 1024, 64, 64, 256, 1) == 512
+    assert _lib.query("cvh_dwx_rows", 1024, 128, 128, 64, 1) == 1024
+    assert _lib.query("cvh_dwx_rows", 1, 8, 16, 64, 1) == 1
+    w = lambda hid, cin: torch.zeros(hid, cin, 1, 1)
+    ok = lambda dt, cin, hid, s, act: fused._dwx_eligible(dt, cin, w(hid, cin), hid, s, act)
+    assert ok(torch.bfloat16, 64, 256, 1, ops.ACT_SILU) and ok(torch.bfloat16, 128, 512, 2, ops.ACT_SILU) and ok(torch.bfloat16, 16, 64, 1, ops.ACT_SILU)
+    assert not ok(torch.float32, 64, 256, 1, ops.ACT_SILU)        # fp32: the y1-storing kernels
+    assert not ok(torch.bfloat16, 96, 384, 1, ops.ACT_SILU)       # stride 1 is instantiated up to 64 input channels
+    assert not ok(torch.bfloat16, 24, 96, 2, ops.ACT_SILU)        # widths of the xx_small model
+    assert not ok(torch.bfloat16, 64, 256, 1, ops.ACT_RELU)       # SiLU-only kernels
+    assert not fused._dwx_eligible(torch.bfloat16, 64, torch.zeros(256, 60, 1, 1), 256, 1, ops.ACT_SILU)  # padded input channels
+
+
+def test_dropout_trace_hook_and_per_task_queue_are_inert_on_cpu():
+    """ops.trace_dropout_sites: a plain Python recorder (p = 0 draws are not recorded); the deferred-reduction queue is per autograd graph
+    task and empty outside a backward pass (finish_backward is idempotent)."""
+    from cvnets_amd import ops
+    sink = []
+    ops.trace_dropout_sites(sink)
+    try:
+        ops._trace_site("linear", 7, 0.1, (4, 8))
+        ops._trace_site("dropout", 8, 0.0, (4, 8))
+    finally:
+        ops.trace_dropout_sites(None)
+    ops._trace_site("linear", 9, 0.5, (1,))
+    assert sink == [("linear", 7, 0.1, (4, 8))]
+    assert ops._pending_by_task == {} and not ops._ensure_backward_callback()   # no graph task is running
+    ops.finish_backward()
+    ops.finish_backward()
+    ops.flush_deferred_reductions()            # outside backward: nothing to do, no error
+    ops.flush_deferred_reductions(task=12345)  # an id that never queued anything
+
+
+def test_bf16_rounding_points_oracle_rounds_where_it_says():
+    """oracle/bf16_points.py (test infrastructure): conv / linear inputs, weights and outputs, activations, LayerNorm, P.V and residual sums are
+    rounded to bf16, gradients through the same points too; scores stay fp32.  On a tiny MobileViT the emulation sits at bf16 distance from
+    the fp32 oracle — not at zero (it rounds) and not far (it rounds only)."""
+    import json
+    import os
+    from oracle import bf16_points, mobilevit_oracle as orc
+    from oracle.weights import seeded_input, seeded_labels, seeded_state_dict
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    sd = seeded_state_dict(json.load(open(os.path.join(gold, "mobilevit_xx_small_keys.json"))), seed=0)
+    x, y = seeded_input((2, 3, 64, 64), seed=11), seeded_labels(2, 1000, seed=11)
+    m = bf16_points.Bf16Points()
+    with m:
+        out = torch.nn.functional.linear(torch.full((1, 3), 1.0 + 2 ** -10), torch.eye(3))
+    assert torch.equal(out, torch.ones(1, 3)) and m.counts == {"linear": 1}     # 1 + 2^-10 rounds to 1 in bf16
+    l32, loss32, g32, _ = orc.train_step(sd, x, y, mode="xx_small")
+    l16, loss16, g16, _ = bf16_points.train_step(sd, x, y, mode="xx_small")
+    rel = float((l16 - l32).norm() / l32.norm())
+    assert 1e-4 < rel < 3e-1, rel
+    assert abs(float(loss16) - float(loss32)) < 1e-1
+    k = "classifier.fc.weight"
+    assert 1e-4 < float((g16[k] - g32[k]).norm() / g32[k].norm()) < 5e-1

@@ -64,3 +64,16 @@ def test_committed_step_profile_belongs_to_this_source_tree():
     fam = {f["family"]: f for f in prof["families"]}
     assert abs(sum(f["ms_per_step"] for f in prof["families"]) - prof["step"]["kernel_time_ms"]) < 0.05 * prof["step"]["kernel_time_ms"]
     assert fam[prof["dominant"]]["launches_per_step"] > 0
+
+
+def test_bench_strong_scaling_keeps_the_global_batch():
+    """--scaling strong (the north-star 8-GPU shard: global batch fixed, per-GPU batch = batch / N): the line says so, the per-GPU work is
+    divided and `value` is still whole-job images over the max-over-ranks time; an indivisible global batch is refused."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--batch", "8", "--scaling", "strong"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _line(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert "4 img/GPU, global batch 8" in out["config"]["workload"] and "strong scaling" in out["config"]["workload"]
+    assert abs(out["value"] - 8 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--batch", "7", "--scaling", "strong"])
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

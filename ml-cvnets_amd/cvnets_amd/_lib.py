@@ -178,7 +178,7 @@ def call(name: str, *args) -> int:
     if _TRACE_CALLS:  # debugging aid (CVH_TRACE_CALLS=1): name every launch before it runs and wait for it — an asynchronous GPU fault is
         import sys     # then reported right after the line of the entry point that caused it
         import torch
-        sys.stderr.write(f"[cvh] {name}\n")
+        sys.stderr.write(f"[cvh] {name} " + " ".join(hex(a) if isinstance(a, int) and a > 0xFFFFFFFF else (repr(a) if isinstance(a, (int, float, type(None))) else type(a).__name__) for a in args) + "\n")
         sys.stderr.flush()
         rc = getattr(load(), name)(*args)
         if not torch.cuda.is_current_stream_capturing():

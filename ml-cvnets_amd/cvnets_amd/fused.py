@@ -300,8 +300,9 @@ class InvertedResidualFn(torch.autograd.Function):
             R = _lib.query("cvh_dwconv_bn_rows", B, Ho, Wo, hid, stride)
             part = _f32(R * 2 * hid, dev)
             dw_part = _f32(R * hid * 9, dev)
+            wpd = ops.pack_weight(wd, dt, 2)  # a named reference: an uncached pack is a temporary, and `_p(temporary)` frees it before the launch
             _lib.call("cvh_dwconv_bn_bwd", _dt(g2t), _p(g2t), _xf(2, y2, coef2[0], coef2[1], coef2[2]), _p(y1), _p(st1), act1,
-                      _p(ops.pack_weight(wd, dt, 2)), _p(g1t), _p(part), _p(dw_part), B, H, W, Ho, Wo, hid, stride, _stream())
+                      _p(wpd), _p(g1t), _p(part), _p(dw_part), B, H, W, Ho, Wo, hid, stride, _stream())
         coef1, dg1, db1 = _bwd_finalize(part, R, hid, M1, g1, st1, pg1, pb1, training)
         sink = ops._grad_sink(wd)
         dwd = None if sink is not None else torch.empty(wd.shape, dtype=torch.float32, device=dev)

@@ -29,6 +29,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+if os.environ.get("CVH_GUARD_ALLOC"):
+    # debugging aid (tools/guard_alloc.cpp): every device allocation in its own address range with unmapped pages on both sides and never
+    # reused after free — an out-of-bounds access or a launch through a stale pointer faults at the launch that does it
+    import torch
+
+    torch.cuda.memory.change_current_allocator(
+        torch.cuda.memory.CUDAPluggableAllocator(os.path.abspath(os.environ["CVH_GUARD_ALLOC"]), "guard_malloc", "guard_free"))
+
+    def _no_capture(*args, **kwargs):
+        pytest.skip("no hipGraph capture under the guard allocator")
+
+    torch.cuda.CUDAGraph = _no_capture
+
+
 if os.environ.get("CVH_TEST_NAN_FILL"):
     # debugging aid: every torch.empty() buffer starts as NaN (floats) / max-int, so a kernel that reads memory it was supposed to
     # write first poisons the result deterministically instead of depending on what the caching allocator handed out
@@ -36,16 +50,3 @@ if os.environ.get("CVH_TEST_NAN_FILL"):
 
     torch.use_deterministic_algorithms(True, warn_only=True)
     torch.utils.deterministic.fill_uninitialized_memory = True
-
-
-@pytest.fixture(autouse=True)
-def _drop_capture_owned_caches(request):
-    """After every GPU test: drop the module-level caches that can hold tensors allocated INSIDE a hipGraph capture (packed weight images
-    re-packed during a captured step, the per-forward dropout-seed snapshot).  A test that captures a graph and lets it die would otherwise
-    leave tensors of a dead private memory pool referenced from module globals for the rest of the process ("Open")."""
-    yield
-    if "gpu" in request.keywords:
-        ops = sys.modules.get("cvnets_amd.ops")
-        if ops is not None:
-            ops._PACKED.clear()
-            ops._seed_snap.clear()

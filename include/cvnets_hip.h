@@ -417,6 +417,34 @@ int cvh_attn_bwd_drop(int dtype, const void* qkv, const void* out, const void* d
                       const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
                       int causal, float drop_p, const unsigned long long* seed, unsigned int stream_id, void* stream);
 
+/* ---- data-parallel exchange on a communicator of its own (RCCL over xGMI) --------------------------------------------------------
+ * Replaces what the reference reaches through torch.distributed: the rendezvous + communicator creation of utils/ddp_utils.py:47-89
+ * (init_process_group("nccl") and the dummy all_reduce at :84-85), the gradient averaging of DistributedDataParallel (main_train.py:91-96),
+ * the parameter / buffer broadcast of its constructor and forward, and the feature gather of the contrastive loss
+ * (loss_fn/multi_modal_img_text/contrastive_loss_clip.py:144-172 through utils/tensor_utils.py:121-122).
+ * One process per GPU; the device that is current at cvh_comm_init is the communicator's device.  `id128` = 128 opaque bytes produced on
+ * rank 0 and carried to the other ranks by the launcher's own key-value rendezvous (cvnets_amd/comm.py uses the TCP store of env://).
+ * Collectives are enqueued on `stream` (stream-ordered, hipGraph-capturable); buffers are device pointers; dtype = CVH_DT_F32 / CVH_DT_BF16,
+ * or CVH_COMM_BYTES for the two that only move data (broadcast, all-gather: counts are then in bytes).
+ * librccl is opened at run time on first use: single-GPU users of this library never load it.
+ * Returns 0, a negative code (-2 arguments, -3 librccl unavailable), a hipError_t, or 1000 + ncclResult_t. */
+#define CVH_COMM_BYTES 100
+int cvh_comm_available(void);                     /* 1 when librccl could be opened and has every entry point used here */
+int cvh_comm_unique_id(void* id128);              /* rank 0: ncclGetUniqueId */
+int cvh_comm_init(void** comm, int world, int rank, const void* id128);  /* every rank: ncclCommInitRank on the current device */
+int cvh_comm_destroy(void* comm);
+int cvh_comm_world(void* comm);
+int cvh_comm_rank(void* comm);
+/* in place: buf = sum over ranks (average != 0: mean over ranks, formed by the collective itself) */
+int cvh_comm_allreduce(void* comm, void* buf, long long count, int dtype, int average, void* stream);
+int cvh_comm_broadcast(void* comm, void* buf, long long count, int dtype, int root, void* stream);
+/* recv[world * count_per_rank] = concatenation of every rank's send[count_per_rank], in rank order */
+int cvh_comm_allgather(void* comm, const void* send, void* recv, long long count_per_rank, int dtype, void* stream);
+/* recv[count_per_rank] = slice `rank` of the sum over ranks of send[world * count_per_rank] */
+int cvh_comm_reducescatter(void* comm, const void* send, void* recv, long long count_per_rank, int dtype, void* stream);
+/* launches so far: out[0..3] = all-reduce, broadcast, all-gather, reduce-scatter (long long[4]); reset != 0 clears */
+int cvh_comm_counters(int reset, long long* out);
+
 /* experiment knob for tools/kernel_bench.py (A/B of kernel variants in one process); never needed for correct results */
 int cvh_set_tuning(int key, int value);
 

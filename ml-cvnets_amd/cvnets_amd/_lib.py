@@ -122,6 +122,17 @@ SIGNATURES = {
     "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "cvh_attn_fwd_drop": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
     "cvh_attn_bwd_drop": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
+    "cvh_comm_available": [],
+    "cvh_comm_unique_id": [P],
+    "cvh_comm_init": [P, I, I, P],
+    "cvh_comm_destroy": [P],
+    "cvh_comm_world": [P],
+    "cvh_comm_rank": [P],
+    "cvh_comm_allreduce": [P, P, L, I, I, P],
+    "cvh_comm_broadcast": [P, P, L, I, I, P],
+    "cvh_comm_allgather": [P, P, P, L, I, P],
+    "cvh_comm_reducescatter": [P, P, P, L, I, P],
+    "cvh_comm_counters": [I, P],
 }
 
 class OperandXf(ctypes.Structure):

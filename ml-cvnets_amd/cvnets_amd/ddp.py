@@ -1,6 +1,11 @@
-"""Data-parallel gradient exchange for the hot path: one process per GPU, RCCL (torch.distributed backend "nccl" on
-ROCm) over xGMI.  Replaces torch.nn.parallel.DistributedDataParallel at main_train.py:90-96 and the rendezvous of
+"""Data-parallel gradient exchange for the hot path: one process per GPU, RCCL over xGMI on a communicator of this package's OWN
+(cvnets_amd/comm.py -> cvh_comm_* in the C ABI: ncclGetUniqueId on rank 0, the 128 bytes carried by the launcher's TCP store,
+ncclCommInitRank on every rank) — every collective of the path (bucket all-reduce, parameter / buffer broadcast, CLIP feature gather) is
+enqueued on a HIP stream through it.  Replaces torch.nn.parallel.DistributedDataParallel at main_train.py:90-96 and the rendezvous of
 utils/ddp_utils.py:47-89 (same contract: ``.module``, parameters/buffers broadcast from rank 0, gradients averaged).
+torch.distributed remains the control plane the reference's engine already uses off this path (barriers, metric reductions), the carrier
+of the unique id, and the data plane of the CPU tests (gloo) — and the fall-back if the communicator cannot be brought up (comm.init_default
+says so on stderr; CVH_OWN_COMM=0 forces it).
 
 Design for the 8-GPU xGMI mesh (7 links x ~153 GB/s per GPU, point-to-point):
   * every parameter gradient lives in a FLAT fp32 bucket (``p.grad`` is a view), so a bucket is one contiguous RCCL
@@ -49,9 +54,53 @@ def distributed_init(backend: Optional[str] = None, device: Optional[torch.devic
     if backend == "nccl" and device is not None:
         kwargs["device_id"] = device
     dist.init_process_group(backend=backend, init_method="env://", **kwargs)
+    if device is not None and device.type == "cuda":
+        from . import comm as _comm
+        with torch.cuda.device(device):
+            own = _comm.init_default(device)  # unique id through the store of the rendezvous above; self-tested (ddp_utils.py:84-85's dummy all-reduce)
+        if own is not None:
+            return dist.get_rank()
     t = torch.zeros(1, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(t)
     return dist.get_rank()
+
+
+class _StreamOrdered:
+    """what `_launch` stores in `bucket.work` for a collective issued through cvnets_amd.comm: it is ordered by the stream it was enqueued
+    on (the side stream, which `finish` joins) — there is no host-side handle to wait for"""
+
+    @staticmethod
+    def wait():
+        return True
+
+
+_STREAM_ORDERED = _StreamOrdered()
+
+
+class _BoundaryPreHook:
+    """forward pre-hook of a top-level child (boundary-driven overlap).  A plain picklable object instead of a closure: copies of the module
+    (torch.save(model), EMA's deepcopy) carry an INERT hook — no reference to the live wrapper, nothing to call."""
+
+    def __init__(self, ddp, ci: int):
+        import weakref
+        self._ddp = weakref.ref(ddp)
+        self.ci = ci
+
+    def __call__(self, mod, args):
+        ddp = self._ddp() if self._ddp is not None else None
+        return None if ddp is None else ddp._pre_forward(self.ci, args)
+
+    def __reduce__(self):
+        return (_inert_boundary_hook, (self.ci,))
+
+    def __deepcopy__(self, memo):
+        return _inert_boundary_hook(self.ci)
+
+
+def _inert_boundary_hook(ci: int) -> "_BoundaryPreHook":
+    h = _BoundaryPreHook.__new__(_BoundaryPreHook)
+    h._ddp, h.ci = None, ci
+    return h
 
 
 class _Bucket:
@@ -95,12 +144,17 @@ class DistributedDataParallel(nn.Module):
         if force_collectives is None:
             force_collectives = os.environ.get("CVH_DDP_FORCE_COLLECTIVES", "0") == "1"
         self.active = dist.is_initialized() and (self.world > 1 or bool(force_collectives))
+        self.comm = None  # the package's own RCCL communicator (GPU runs); None: torch.distributed carries the data (gloo CPU tests, fall-back)
         self.overlap = overlap
         self.broadcast_buffers = broadcast_buffers
         params = [p for p in module.parameters() if p.requires_grad]
         self.device = params[0].device
         self.use_side_stream = self.device.type == "cuda"
         self.side_stream = torch.cuda.Stream(device=self.device) if self.use_side_stream else None
+        if self.active and self.device.type == "cuda" and process_group is None:
+            from . import comm as _comm
+            with torch.cuda.device(self.device):
+                self.comm = _comm.init_default(self.device)
         # float buffers -> views of one flat tensor (one broadcast message per forward, no torch.cat / copy-back)
         fbufs = [b for b in module.buffers() if b.dtype.is_floating_point and b.device == self.device]
         self.flat_buffers = None
@@ -116,7 +170,10 @@ class DistributedDataParallel(nn.Module):
         # parameters + buffers start identical on every rank (DDP ctor broadcast)
         if self.active:
             for t in list(module.parameters()) + [b for b in module.buffers()]:
-                dist.broadcast(t.data, src=0, group=self.pg)
+                if self.comm is not None and t.data.is_contiguous():
+                    self.comm.broadcast(t.data, 0)
+                else:
+                    dist.broadcast(t.data, src=0, group=self.pg)
         self._avg_op = dist.ReduceOp.AVG if (dist.is_initialized() and dist.get_backend(self.pg) == "nccl") else None
         # buckets in reverse registration order: the last layers' gradients are ready first
         cap = int(bucket_cap_mb * 1024 * 1024 / 4)
@@ -168,17 +225,18 @@ class DistributedDataParallel(nn.Module):
                 if p in owner:  # a parameter shared between top-level children: its gradient is complete only at the earlier one
                     return
                 owner[p] = ci
-        if any(p not in owner for b in self.buckets for p in b.params):
-            return  # parameters registered directly on the root module
         for b in self.buckets:
+            # a parameter registered directly on the root module (ViT / CLIP: cls_token) can be used anywhere in forward: its gradient is
+            # complete only at the end of backward — the bucket that holds it belongs to no boundary and is launched by `finish`
+            if any(p not in owner for p in b.params):
+                continue
             ci = min(owner[p] for p in b.params)
             self._boundary_buckets.setdefault(ci, []).append(b)
-        for ci, ch in enumerate(children):
-            ch.register_forward_pre_hook(lambda mod, args, ci=ci: self._pre_forward(ci, args))
+        self._boundary_handles = [ch.register_forward_pre_hook(_BoundaryPreHook(self, ci)) for ci, ch in enumerate(children)]
         self.boundary_overlap = True
 
     def _pre_forward(self, ci: int, args):
-        if not self.boundary_overlap:
+        if not self.boundary_overlap or self._in_no_sync:
             return None
         if ci == 0:
             self._boundary_seen = 0
@@ -195,12 +253,13 @@ class DistributedDataParallel(nn.Module):
         return None
 
     boundary_enabled = True
+    _in_no_sync = False
 
     def _boundary(self, ci: int):
         """backward has produced the gradient w.r.t. the input of child `ci`: every parameter of children >= ci has its gradient kernels
         (or deferred partial sums) enqueued"""
-        if not (self.active and self.boundary_overlap and self.boundary_enabled):
-            return None
+        if not (self.active and self.boundary_overlap and self.boundary_enabled) or self._in_no_sync:
+            return None  # (no_sync: the micro-steps of a gradient accumulation exchange nothing — torch DDP's contract)
         tid = torch._C._current_graph_task_id()
         if self._callback_task != tid:
             if self._callback_task is not None:
@@ -237,12 +296,12 @@ class DistributedDataParallel(nn.Module):
         Enter it OUTSIDE a backward pass (a backward already in progress has its exchange queued)."""
         if torch._C._current_graph_task_id() >= 0:
             raise RuntimeError("cvnets_amd.ddp.no_sync() must be entered outside a backward pass")
-        prev = self.hooks_enabled
-        self.hooks_enabled = False
+        prev = (self.hooks_enabled, self._in_no_sync)
+        self.hooks_enabled, self._in_no_sync = False, True
         try:
             yield
         finally:
-            self.hooks_enabled = prev
+            self.hooks_enabled, self._in_no_sync = prev
 
     # ---- autograd-driven path (eager) --------------------------------------------------------
     def _hook(self, p: nn.Parameter):
@@ -264,16 +323,18 @@ class DistributedDataParallel(nn.Module):
         b.adopt_stray_grads()
         op = self._avg_op if self._avg_op is not None else dist.ReduceOp.SUM
         if self.use_side_stream:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self.side_stream.wait_event(ev)
-            with torch.cuda.stream(self.side_stream):
-                b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
+            self.side_stream.wait_stream(torch.cuda.current_stream(self.device))  # fork: everything enqueued so far precedes the message
+            if self.comm is not None:
+                self.comm.all_reduce(b.flat, average=True, stream=self.side_stream)  # ncclAllReduce(ncclAvg) on the side stream
+                b.work = _STREAM_ORDERED
+            else:
+                with torch.cuda.stream(self.side_stream):
+                    b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         else:
             b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
 
     def _average(self):
-        if self._avg_op is None:  # gloo (CPU tests): no AVG reduction
+        if self._avg_op is None and self.comm is None:  # gloo (CPU tests): no AVG reduction
             for b in self.buckets:
                 b.flat.div_(self.world)
 
@@ -320,7 +381,7 @@ class DistributedDataParallel(nn.Module):
         new.pg, new.world, new.active, new.overlap, new.broadcast_buffers = None, 1, False, False, False
         new.device = self.device
         new.use_side_stream, new.side_stream, new.flat_buffers, new._buf_span = False, None, None, None
-        new._avg_op, new.buckets, new._bucket_of = None, [], {}
+        new._avg_op, new.buckets, new._bucket_of, new.comm = None, [], {}, None
         new._callback_task, new.hooks_enabled = None, False
         new.early_launches = new.late_launches = new.finish_count = 0
         new._warned_no_overlap = True
@@ -378,11 +439,17 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self.broadcast_buffers and self.active and self.training:
             if self.flat_buffers is not None and self._buffers_still_flat():
-                dist.broadcast(self.flat_buffers, src=0, group=self.pg)  # the buffers ARE views of this tensor
+                if self.comm is not None:
+                    self.comm.broadcast(self.flat_buffers, 0)  # the buffers ARE views of this tensor: one message on the compute stream
+                else:
+                    dist.broadcast(self.flat_buffers, src=0, group=self.pg)
             else:
                 for b in self.module.buffers():
                     if b.dtype.is_floating_point:
-                        dist.broadcast(b.data, src=0, group=self.pg)
+                        if self.comm is not None and b.data.is_contiguous():
+                            self.comm.broadcast(b.data, 0)
+                        else:
+                            dist.broadcast(b.data, src=0, group=self.pg)
         return self.module(*args, **kwargs)
 
 
@@ -395,6 +462,18 @@ def _rebuild_passive(module: nn.Module, training: bool) -> DistributedDataParall
     return new
 
 
+def _own_comm(x: torch.Tensor, group):
+    """the package's communicator for a collective over the DEFAULT group on GPU float tensors (None: torch.distributed carries it)"""
+    if group is not None or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    from . import comm as _comm
+    c = _comm.default()
+    if c is None and dist.is_initialized():
+        with torch.cuda.device(x.device):
+            c = _comm.init_default(x.device)
+    return c if (c is not None and c.world == dist.get_world_size()) else None
+
+
 class _AllGatherWithGrad(torch.autograd.Function):
     """utils/tensor_utils.py:121-122 (gather_all_features -> torch.distributed.nn.all_gather): forward = all-gather along dim 0
     (one RCCL collective into a contiguous [W*N, d] buffer), backward = reduce-scatter(sum) of the gathered gradient — every rank
@@ -405,7 +484,11 @@ class _AllGatherWithGrad(torch.autograd.Function):
         x = x.contiguous()
         world = dist.get_world_size(group)
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=group)
+        ctx.comm = _own_comm(x, group)
+        if ctx.comm is not None:
+            ctx.comm.all_gather(out, x)
+        else:
+            dist.all_gather_into_tensor(out, x, group=group)
         ctx.group = group
         ctx.n = x.shape[0]
         return out
@@ -418,7 +501,10 @@ class _AllGatherWithGrad(torch.autograd.Function):
             dist.all_reduce(g, group=ctx.group)
             return g[rank * ctx.n:(rank + 1) * ctx.n].clone(), None
         out = torch.empty((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.reduce_scatter_tensor(out, g, group=ctx.group)
+        if ctx.comm is not None:
+            ctx.comm.reduce_scatter(out, g)
+        else:
+            dist.reduce_scatter_tensor(out, g, group=ctx.group)
         return out, None
 
 

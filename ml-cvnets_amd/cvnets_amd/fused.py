@@ -338,14 +338,19 @@ def inverted_residual(x, exp, dw, red, *, stride: int, use_res: bool):
     (c1, n1, a1), (cd, n2, a2), (c3, n3, _) = exp, dw, red
     training = n1.training or not n1.track_running_stats
     cfg = (int(stride), bool(use_res), bool(training), int(a1), int(a2), (n1.momentum, n2.momentum, n3.momentum), (n1.eps, n2.eps, n3.eps))
-    # `_cvh_colsum`: column sums a previous fused block attached to ITS output tensor (valid only for that very tensor object)
-    xsum = getattr(x, "_cvh_colsum", None)
-    if xsum is not None and (xsum.numel() != x.shape[1] or xsum.device != x.device):
-        xsum = None
+    # `_cvh_colsum`: column sums a previous fused block attached to ITS output tensor, with the tensor's version counter and address at that
+    # moment: an in-place modification between the blocks (a user hook, .add_ / .mul_, in-place dropout or stochastic depth) bumps the
+    # version and the analytic sums are dropped — the next block then forms its column sums from the data (gram_bn_stats)
+    xsum = None
+    tag = getattr(x, "_cvh_colsum", None)
+    if tag is not None:
+        osum0, ver0, ptr0 = tag
+        if ver0 == x._version and ptr0 == x.data_ptr() and osum0.numel() == x.shape[1] and osum0.device == x.device:
+            xsum = osum0
     res = InvertedResidualFn.apply(x, c1.weight, n1.weight, n1.bias, n1.running_mean, n1.running_var, cd.weight, n2.weight, n2.bias,
                                    n2.running_mean, n2.running_var, c3.weight, n3.weight, n3.bias, n3.running_mean, n3.running_var, cfg, xsum)
     if isinstance(res, tuple):
         out, osum = res
-        out._cvh_colsum = osum
+        out._cvh_colsum = (osum, out._version, out.data_ptr())
         return out
     return res

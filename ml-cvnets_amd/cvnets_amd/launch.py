@@ -46,7 +46,15 @@ def distributed_init(opts) -> int:
             kwargs["device_id"] = device  # eager communicator creation on THIS GPU; no device guessing inside RCCL
         dist.init_process_group(backend=backend, init_method=ddp_url, world_size=world_size, rank=node_rank, **kwargs)
         if torch.cuda.is_available() and backend == "nccl":
-            dist.all_reduce(torch.zeros(1, device=device if kwargs else "cuda"))  # ddp_utils.py:84-85
+            # ddp_utils.py:84-85 creates the communicator with a dummy all-reduce.  Here the hot path gets a communicator of its own: the
+            # unique id travels through the TCP store this rendezvous just opened, every rank joins, one self-test all-reduce + broadcast
+            # (cvnets_amd/comm.py).  The torch group stays for what the engine does off the path (barriers, metric reductions).
+            from . import comm as hip_comm
+
+            dev = device if kwargs else torch.device("cuda", torch.cuda.current_device())
+            with torch.cuda.device(dev):
+                if hip_comm.init_default(dev) is None:
+                    dist.all_reduce(torch.zeros(1, device=dev))
     node_rank = dist.get_rank()
     setattr(opts, "ddp.rank", node_rank)
     return node_rank

@@ -40,8 +40,8 @@ def set_compute_dtype(dtype: Optional[torch.dtype]) -> None:
 def compute_dtype() -> torch.dtype:
     if _COMPUTE_DTYPE is not None:
         return _COMPUTE_DTYPE
-    if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
         if dt == torch.bfloat16:
             return torch.bfloat16
         raise RuntimeError("cvnets_amd supports bfloat16 autocast only (set common.mixed_precision_dtype=bfloat16)")
@@ -224,7 +224,10 @@ def dropout_keep_scale(seed: torch.Tensor, stream_id: int, shape, p: float) -> t
 # ------------------------------------------------------------------------------------------------
 # weight packing
 # ------------------------------------------------------------------------------------------------
-_PACKED = {}  # (data_ptr, mode, dtype) -> (packed view, parameter version it was packed from, weakref to the parameter, pack epoch)
+# Packed weight images are owned by the model: a PackPlan (module.__dict__["_cvh_pack_plan"]) holds the flat buffer, and this table maps a
+# live PARAMETER OBJECT to the views cut for it — id(parameter) -> (weakref to the parameter, {(mode, dtype): (view, version, epoch)}).  The
+# entry is removed by a finalizer when the parameter dies, so nothing of a dead model (its pack buffer included) stays referenced.
+_PACKED = {}
 _PACK_EPOCH = 0  # bumped by everything that rewrites parameters through raw pointers (cvh_adamw_multi, EMA kernels): `_version` cannot see those
 
 
@@ -234,6 +237,23 @@ def invalidate_packed() -> None:
     a model-level forward — the model-level forwards re-pack unconditionally)."""
     global _PACK_EPOCH
     _PACK_EPOCH += 1
+
+
+def _drop_packs(key: int, slot) -> None:
+    if _PACKED.get(key) is slot:
+        del _PACKED[key]
+
+
+def _pack_slot(w: torch.Tensor, create: bool):
+    slot = _PACKED.get(id(w))
+    if slot is not None and slot[0]() is w:
+        return slot[1]
+    if not create:
+        return None
+    slot = (weakref.ref(w), {})
+    _PACKED[id(w)] = slot  # (an entry left by a dead parameter whose id was reused is replaced; its own finalizer then finds another slot)
+    weakref.finalize(w, _drop_packs, id(w), slot)
+    return slot[1]
 
 
 def _pack_numel(shape, mode: int) -> int:
@@ -298,7 +318,7 @@ class PackPlan:
             return
         _lib.call("cvh_weight_pack_multi", _dt(self.flat), _p(self.table), len(self.entries), self.total, _p(self.flat), _stream())
         for (w, mode), (off, n) in zip(self.entries, self.offsets):
-            _PACKED[(w.data_ptr(), mode, self.dtype)] = (self.flat[off: off + n], w._version, weakref.ref(w), _PACK_EPOCH)
+            _pack_slot(w, True)[(mode, self.dtype)] = (self.flat[off: off + n], w._version, _PACK_EPOCH)
 
 
 def pack_all(module: torch.nn.Module, dtype: Optional[torch.dtype] = None) -> None:
@@ -362,8 +382,9 @@ def _grad_sink(param: Optional[torch.Tensor]):
 
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, mode: int) -> torch.Tensor:
     """mode 0: [Cout][KH*KW][pad8(Cin)] ; mode 1: [Cin][KH*KW][pad8(Cout)] (taps flipped) ; mode 2: depthwise [KH*KW][C]."""
-    hit = _PACKED.get((w.data_ptr(), mode, dtype))
-    if hit is not None and hit[1] == w._version and hit[2]() is w and hit[3] == _PACK_EPOCH:
+    slot = _pack_slot(w, False)
+    hit = slot.get((mode, dtype)) if slot is not None else None
+    if hit is not None and hit[1] == w._version and hit[2] == _PACK_EPOCH:
         return hit[0]
     wf = w.detach()
     if wf.dtype != torch.float32 or not wf.is_contiguous():
@@ -515,6 +536,9 @@ def flush_deferred_reductions(task: Optional[int] = None) -> None:
     the order of the engine's final callbacks is the order in which they were queued, not ours to choose)"""
     tid = torch._C._current_graph_task_id() if task is None else task
     if tid >= 0:
+        # the partial buffers (and, undeferred, the .grad sinks) may have been written on the parameter-gradient side stream (CVH_ASYNC_DW=1):
+        # the reduction below — and the bucket all-reduce the caller is about to start — must come after those kernels
+        _join_param_grad_stream()
         _flush_deferred_reductions(tid)
 
 

@@ -29,6 +29,24 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def _references_without_miopen():
+    """The torch REFERENCE computations of the GPU tests (F.conv2d / batch_norm + autograd on the device) must not run MIOpen's solvers.
+    Root cause of the asynchronous "Memory access fault by GPU" that rounds 3-4 saw in this suite: for the float32 1x1 convolution
+    [2, 16, 6, 6] x [24, 16, 1, 1] of tests/test_kernels_gpu.py::test_bn_eval_mode, MIOpen's backward-data solver
+    `igemm_bwd_gtcx35_nhwc_fp32_bx0_ex1_bt128x32x8_...` reads past the end of its operands.  Inside the caching allocator's segments that is
+    invisible; when the tensor happens to end a segment that is followed by an unmapped range (allocation history = test order) the GPU
+    faults.  tools/guard_aten_repro.py reproduces it with torch alone (no kernel of this repository runs) under the guard-page allocator
+    and passes with MIOpen off; profiles/r05_fault_root_cause.txt has the runs.  The product never calls MIOpen."""
+    try:
+        import torch
+        torch.backends.cudnn.enabled = False  # ("cudnn" is MIOpen on ROCm): ATen's native convolution / batch-norm kernels instead
+    except Exception:  # pragma: no cover
+        pass
+
+
+_references_without_miopen()
+
+
 if os.environ.get("CVH_GUARD_ALLOC"):
     # debugging aid (tools/guard_alloc.cpp): every device allocation in its own address range with unmapped pages on both sides and never
     # reused after free — an out-of-bounds access or a launch through a stale pointer faults at the launch that does it

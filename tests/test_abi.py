@@ -22,6 +22,8 @@ def header_prototypes():
         types = []
         for a in args.split(","):
             a = " ".join(a.split())
+            if a == "void":  # f(void)
+                continue
             if "*" in a:
                 types.append(ctypes.c_void_p)
             else:

@@ -203,3 +203,60 @@ def test_ddp_wrapper_can_be_copied_and_pickled():
         assert c(torch.randn(4, 16)).shape == (4, 8)
         for a, b in zip(c.parameters(), ddp.parameters()):  # the reference's EMA update (averaging_utils.py:43-55)
             a.detach().mul_(0.5).add_(b.detach(), alpha=0.5)
+
+
+class _RootParamNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(16, 32)
+        self.b = torch.nn.Linear(32, 8)
+        self.cls_token = torch.nn.Parameter(torch.zeros(1, 8))  # root-level parameter
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x))) + self.cls_token
+
+
+def test_boundary_overlap_wrapper_copy_pickle_no_sync_and_root_parameters():
+    """(a) with boundary_overlap the top-level children carry forward pre-hooks — a copy / pickle of the wrapper must carry
+    INERT hooks (no closure to pickle, no reference to the live wrapper whose order bookkeeping a forward of the copy could disturb);
+    (b) no_sync() silences the boundary-driven exchange as well (torch DDP's contract: nothing is communicated inside it);
+    (c) a parameter registered on the ROOT module (ViT / CLIP cls_token) no longer switches the feature off: its bucket belongs to no
+    boundary and is launched at the end of backward."""
+    import copy
+    import pickle
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    from cvnets_amd.ddp import DistributedDataParallel
+
+    Net = _RootParamNet
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", init_method="env://")
+    try:
+        net = Net()
+        ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001, first_bucket_mb=0.0001, boundary_overlap=True, force_collectives=True)
+        assert ddp.boundary_overlap and ddp.active                                  # (c): not switched off by cls_token
+        owned = [b for lst in ddp._boundary_buckets.values() for b in lst]
+        root_bucket = ddp._bucket_of[net.cls_token]
+        assert root_bucket not in owned and len(owned) >= 2
+        ddp.hooks_enabled = False                                                   # in-place-gradient regime: boundaries only
+        x = torch.randn(4, 16).requires_grad_(True)
+        e0, l0 = ddp.early_launches, ddp.late_launches
+        ddp.zero_grad()
+        ddp(x).square().mean().backward()
+        assert ddp.early_launches > e0 and ddp.late_launches > l0                   # boundary buckets early, the root-level one in finish()
+        want = [p.grad.clone() for p in net.parameters()]
+        # (b) no_sync: no launch of any kind, gradients accumulate locally
+        e1, l1, f1 = ddp.early_launches, ddp.late_launches, ddp.finish_count
+        with ddp.no_sync():
+            ddp(x).square().mean().backward()
+        assert (ddp.early_launches, ddp.late_launches, ddp.finish_count) == (e1, l1, f1)
+        for p, w in zip(net.parameters(), want):
+            assert torch.allclose(p.grad, 2 * w)
+        # (a) copies
+        seen = ddp._boundary_seen
+        for c in (copy.deepcopy(ddp), pickle.loads(pickle.dumps(ddp))):
+            assert not c.active and not c.boundary_overlap
+            c(torch.randn(2, 16))                                                   # the copy's (inert) hooks run
+            assert ddp._boundary_seen == seen and ddp.boundary_overlap             # ... and did not touch the live wrapper
+    finally:
+        dist.destroy_process_group()

@@ -1,5 +1,7 @@
-"""The GPU side of cvnets_amd/ddp.py executed on ONE GPU (SURVEY.md §8 rows a15 / e): a single-rank RCCL group ("nccl" backend bound to
-the device) whose collectives are issued anyway (`force_collectives`).  An all-reduce over one rank is an identity — which is exactly
+"""The GPU side of cvnets_amd/ddp.py and cvnets_amd/comm.py executed on ONE GPU (SURVEY.md §8 rows a15 / e): a single-rank world whose
+collectives are issued anyway (`force_collectives`) — through the package's OWN RCCL communicator (cvh_comm_* in the C ABI: unique id,
+ncclCommInitRank, ncclAllReduce(ncclAvg) / ncclBroadcast / ncclAllGather / ncclReduceScatter on HIP streams), with torch.distributed
+("nccl" group bound to the device) left as the control plane.  An all-reduce over one rank is an identity — which is exactly
 what makes it checkable: every result must equal the no-DDP result bit for bit — but it runs the communicator, `ReduceOp.AVG`, the side
 HIP stream with its event ordering, the autograd hooks, `finish`, hipGraph capture of RCCL kernels next to the RCCL watchdog thread,
 and the all-gather / reduce-scatter pair of the contrastive loss.  Multi-GPU runs are the driver's (replaces main_train.py:90-96,
@@ -27,9 +29,12 @@ def rccl_world1():
         setattr(opts, k, v)
     torch.cuda.set_device(0)
     assert not dist.is_initialized()
+    from cvnets_amd import comm
     rank = launch.distributed_init(opts)          # the launcher's replacement of utils/ddp_utils.py:47-89
     assert rank == 0 and dist.get_backend() == "nccl" and getattr(opts, "ddp.dist_url") == f"tcp://127.0.0.1:{port}"
+    assert comm.default() is not None and comm.default().world == 1   # the hot path's own communicator came up (and passed its self-test)
     yield opts
+    comm.destroy_default()
     dist.destroy_process_group()
 
 
@@ -50,17 +55,65 @@ def _batch(B=4, res=64, seed=5):
 
 
 class _Count:
-    """counts the collectives that reach torch.distributed (and checks the reduction op)"""
+    """counts the bucket all-reduces: `n` = launches through the package's communicator (tallied inside the library, cvh_comm_counters),
+    `torch_n` = calls that reached torch.distributed instead (must stay 0 on the GPU path)"""
 
     def __init__(self, monkeypatch):
-        self.n, self.ops = 0, []
+        from cvnets_amd import comm
+        self._comm = comm
+        self.torch_n = 0
+        self._base = comm.counters()[0]
         orig = dist.all_reduce
 
         def wrapped(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-            self.n += 1
-            self.ops.append(op)
+            self.torch_n += 1
             return orig(t, op=op, group=group, async_op=async_op)
         monkeypatch.setattr(dist, "all_reduce", wrapped)
+
+    @property
+    def n(self):
+        return self._comm.counters()[0] - self._base
+
+    @n.setter
+    def n(self, v):
+        assert v == 0
+        self._base = self._comm.counters()[0]
+
+
+def test_own_communicator_collectives(rccl_world1):
+    """cvnets_amd.comm.Communicator in a world of one: every collective runs RCCL's kernel on the given stream and is an identity (all-gather
+    / reduce-scatter: a copy), float32 and bfloat16; broadcast also moves opaque bytes (int64 BatchNorm counters)."""
+    from cvnets_amd import comm
+    c = comm.default()
+    assert comm.available() and c.rank == 0
+    before = comm.counters()
+    side = torch.cuda.Stream()
+    for dtype in (torch.float32, torch.bfloat16):
+        t = torch.randn(3001, device="cuda").to(dtype)
+        want = t.clone()
+        c.all_reduce(t)
+        c.all_reduce(t, average=True)
+        side.wait_stream(torch.cuda.current_stream())
+        c.all_reduce(t, average=True, stream=side)      # the side-stream form ddp uses
+        torch.cuda.current_stream().wait_stream(side)
+        c.broadcast(t, 0)
+        out = torch.empty_like(t)
+        c.all_gather(out, t)
+        rs = torch.empty_like(t)
+        c.reduce_scatter(rs, out)
+        torch.cuda.synchronize()
+        assert torch.equal(t, want) and torch.equal(out, want) and torch.equal(rs, want)
+    n = torch.arange(17, device="cuda", dtype=torch.int64)
+    c.broadcast(n, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(n, torch.arange(17, device="cuda"))
+    after = comm.counters()
+    assert tuple(a - b for a, b in zip(after, before)) == (6, 3, 2, 2)
+    with pytest.raises(RuntimeError):
+        c.all_reduce(n)                                   # integer reductions are not on the path
+    with pytest.raises(RuntimeError):
+        c.all_reduce(torch.zeros(4, 4, device="cuda").t())  # one message = one contiguous buffer
+    c.self_test()
 
 
 def test_eager_hooks_side_stream_allreduce_avg(rccl_world1, monkeypatch):
@@ -76,7 +129,7 @@ def test_eager_hooks_side_stream_allreduce_avg(rccl_world1, monkeypatch):
         want = {k: p.grad.clone() for k, p in ref.named_parameters()}
         m = _model()
         ddp = DistributedDataParallel(m, bucket_cap_mb=1.0, force_collectives=True)   # 1 MB cap: several buckets, launched as they fill
-        assert ddp.active and len(ddp.buckets) >= 3 and ddp._avg_op == dist.ReduceOp.AVG
+        assert ddp.active and len(ddp.buckets) >= 3 and ddp.comm is not None
         cnt = _Count(monkeypatch)
         for _ in range(2):  # twice: bucket bookkeeping resets in finish()
             ddp.zero_grad()
@@ -87,7 +140,7 @@ def test_eager_hooks_side_stream_allreduce_avg(rccl_world1, monkeypatch):
                 assert any(lo <= p.grad.data_ptr() < hi for lo, hi in lo_hi), k   # gradients are views of the flat buckets
                 # AVG over one rank is the identity: equal to the plain backward up to the run-to-run order of the fp32 atomics
                 assert torch.allclose(p.grad, want[k], rtol=1e-4, atol=1e-6 + 1e-5 * float(want[k].abs().max())), k
-        assert cnt.n == 2 * len(ddp.buckets) and all(o == dist.ReduceOp.AVG for o in cnt.ops)
+        assert cnt.n == 2 * len(ddp.buckets) and cnt.torch_n == 0   # every bucket through cvh_comm_allreduce (ncclAvg), none through torch
         # gradient accumulation: nothing is reduced inside no_sync()
         cnt.n = 0
         ddp.zero_grad()

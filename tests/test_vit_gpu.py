@@ -171,7 +171,8 @@ def test_embed_lookup(dtype):
     assert l2_err(out.float().cpu(), ref.view(B * S, E)) < (1e-6 if dtype == torch.float32 else 8e-3)
     dout = torch.randn(B * S, E, generator=g).to(dtype)
     dtab = torch.zeros(V, E, device="cuda")
-    _lib.call("cvh_embed_lookup_bwd", _dt(out), _p(tk), _p(dout.cuda()), _p(dtab), B * S, E, 0, _stream())
+    dg = dout.cuda()  # a named reference: `_p(dout.cuda())` hands the kernel the address of a tensor that is freed before the launch
+    _lib.call("cvh_embed_lookup_bwd", _dt(out), _p(tk), _p(dg), _p(dtab), B * S, E, 0, _stream())
     dref = torch.zeros(V, E).index_add_(0, tok.view(-1), dout.float())
     dref[0] = 0  # padding_idx rows receive no gradient (nn.Embedding(padding_idx=0))
     assert l2_err(dtab.cpu(), dref) < 1e-5

@@ -72,7 +72,10 @@ struct DwxFwdParams {
 // LDS pitch of the x tiles: dense rows for one 32-wide K step (2-way conflicts on the operand reads, 4 workgroups per CU), + 16 B otherwise
 template <int CIN> __host__ __device__ constexpr int dx_xp() { return 32 * ((CIN + 31) / 32) + (CIN <= 32 ? 0 : 8); }
 // x tile buffers of the forward kernel (see the tile loop)
-template <int CIN> __host__ __device__ constexpr int dx_xbuf() { return CIN <= 64 ? 2 : 1; }
+#ifndef DX_XBUF64
+#define DX_XBUF64 2
+#endif
+template <int CIN> __host__ __device__ constexpr int dx_xbuf() { return CIN <= 32 ? 2 : (CIN <= 64 ? DX_XBUF64 : 1); }
 // waves per SIMD the register allocator is held to (= workgroups per CU the LDS footprint allows)
 #ifndef DX_OCC_A
 #define DX_OCC_A 4

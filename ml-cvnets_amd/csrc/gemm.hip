@@ -113,7 +113,13 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   if (dtype == CVH_DT_BF16 && conv3x3_eligible(p)) return launch_conv3x3(p, cvh_conv_gemm_grid_rows(p.M, N), st);  // MobileViT-block 3x3 convs
   if (dtype == CVH_DT_BF16 && gemm_stream_eligible(p)) return launch_gemm_stream(p, st);  // short-K token linears / 1x1 convs (MobileViT blocks)
   if (dtype == CVH_DT_BF16 && gemm_big_eligible(p)) return launch_gemm_big(p, st);  // transformer-sized linears (ViT-B / CLIP)
-  const int nf = choose_nf(N);
+  int nf = choose_nf(N);
+  if (const int fill = cvh_tune_get(CVH_TUNE_GEMM_FILL); fill > 0) {
+    // small-M problems (the 128-image shard of an 8-GPU run: layer_4 / layer_5 convolutions with 8 k - 32 k rows): the widest N tile leaves
+    // most CUs without a workgroup — narrower tiles re-read the (L2-resident) A panel but fill the chip
+    const int mt = (p.M + 127) / 128;
+    while (nf > 1 && (long long)mt * ((N + 32 * nf - 1) / (32 * nf)) < fill) --nf;
+  }
   const bool bk64 = p.Ktot >= 64;
   if (dtype == CVH_DT_BF16 && src2 == nullptr && KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.Ktot <= 64 && p.M >= 4096 &&
       !cvh_tune_get(CVH_TUNE_NO_WAVE_PRIVATE)) {

@@ -316,6 +316,11 @@ class DistributedDataParallel(nn.Module):
         b = self._bucket_of[p]
         b.pending -= 1
         if b.pending == 0 and self.overlap:
+            from . import ops
+            if ops._INPLACE_PARAM_GRADS:
+                # (the hook of a parameter whose gradient the kernels added in place fires with an undefined gradient on current PyTorch:)
+                # the partial sums of its weight gradient may still sit in the deferred-reduction queue — reduce them before the message leaves
+                ops.flush_deferred_reductions()
             self.early_launches += 1
             self._launch(b)
 
@@ -450,7 +455,38 @@ class DistributedDataParallel(nn.Module):
                             self.comm.broadcast(b.data, 0)
                         else:
                             dist.broadcast(b.data, src=0, group=self.pg)
-        return self.module(*args, **kwargs)
+        out = self.module(*args, **kwargs)
+        if self.active and self.hooks_enabled and not self._in_no_sync and torch.is_grad_enabled():
+            from . import ops
+            if ops._INPLACE_PARAM_GRADS:
+                # in-place parameter gradients never reach autograd, so no post-accumulate hook will queue `finish`: a hook on the output
+                # does it when backward starts (buckets not started by a boundary are then exchanged at the end of backward)
+                t = _first_tensor(out)
+                if t is not None and t.requires_grad:
+                    t.register_hook(self._backward_started)
+        return out
+
+    def _backward_started(self, grad):
+        tid = torch._C._current_graph_task_id()
+        if tid >= 0 and self._callback_task != tid and self.active and self.hooks_enabled and not self._in_no_sync:
+            if self._callback_task is not None:
+                self._discard_stale_task()
+            self._callback_task = tid
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        return None
+
+
+def _first_tensor(out):
+    if isinstance(out, torch.Tensor):
+        return out
+    if isinstance(out, dict):
+        out = list(out.values())
+    if isinstance(out, (list, tuple)):
+        for o in out:
+            t = _first_tensor(o)
+            if t is not None:
+                return t
+    return None
 
 
 def _rebuild_passive(module: nn.Module, training: bool) -> DistributedDataParallel:

@@ -20,6 +20,7 @@ The reference tree must be importable (``PYTHONPATH=/path/to/ml-cvnets``); this 
 from __future__ import annotations
 
 import argparse
+import os
 import math
 from typing import Callable, List, Optional
 
@@ -117,13 +118,28 @@ def main(opts: argparse.Namespace, *, swap: Optional[bool] = None, loader_factor
     elif use_distributed:
         # substitution 2: flat-bucket RCCL data parallelism.  Wrap BEFORE EMA / optimizer construction: the wrapper re-points gradient
         # and buffer storage into its flat tensors.
-        model = hip_ddp.DistributedDataParallel(model)
+        # boundary_overlap: with the fused optimizer below the kernels add parameter gradients in place (no per-parameter autograd hooks);
+        # the buckets then start when backward passes the inputs of the model's top-level children, the rest at the end of backward
+        model = hip_ddp.DistributedDataParallel(model, boundary_overlap=True)
         if is_master_node:
             logger.log("Using cvnets_amd.ddp.DistributedDataParallel (RCCL, {} bucket(s), {:.1f} MB of gradients)".format(
                 len(model.buckets), model.grad_bytes() / 1e6))
 
     criteria = build_loss_fn(opts).to(device=device)
     optimizer = build_optimizer(model, opts=opts)
+    # substitution 4: when the YAML asks for AdamW on the GPU, the reference's Trainer steps cvnets_amd.optim.AdamW — one
+    # cvh_adamw_multi launch over every parameter instead of torch's per-tensor / foreach kernels — and the gradients live in one flat
+    # buffer the backward kernels add into (no per-parameter AccumulateGrad work; `zero_grad(set_to_none=True)` becomes one memset).
+    # Same param_groups, so the reference's scheduler and checkpointing see what they expect.  CVH_ENGINE_FUSED_OPT=0 keeps torch's.
+    if swap and isinstance(device, torch.device) and device.type == "cuda" and os.environ.get("CVH_ENGINE_FUSED_OPT", "1") != "0" \
+            and isinstance(optimizer, torch.optim.AdamW) and not any(g.get("amsgrad", False) for g in optimizer.param_groups):
+        from . import ops as hip_ops
+        from . import optim as hip_optim
+
+        optimizer = hip_optim.AdamW.from_torch(optimizer, flat_grads=True)
+        hip_ops.set_inplace_param_grads(True)
+        if is_master_node:
+            logger.log("cvnets_amd: optimizer AdamW -> cvnets_amd.optim.AdamW (one launch per step, flat in-place gradients)")
     gradient_scaler = GradScaler(enabled=getattr(opts, "common.mixed_precision"))
     scheduler = build_scheduler(opts=opts)
 

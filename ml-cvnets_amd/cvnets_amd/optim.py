@@ -27,6 +27,60 @@ class AdamW(torch.optim.Optimizer):
         self._rebuilds = 0
         self._ema = ema
         self.ema_momentum = float(ema_momentum)
+        self._flat = None  # (flat fp32 buffer, [(parameter, view)]) when this optimizer owns the gradient storage (`flat_grads`)
+
+    # ---- engine-driven use (cvnets_amd/launch.py): the reference's Trainer owns the loop, this object the gradient storage -------------
+    @classmethod
+    def from_torch(cls, optimizer: torch.optim.Optimizer, flat_grads: bool = True) -> "AdamW":
+        """A fused AdamW with the parameter groups (parameters, lr, weight_decay, betas, eps — every other key rides along untouched, so a
+        scheduler that rewrites ``param_groups[i]["lr"]`` keeps working) of a torch.optim.AdamW built by the reference's
+        ``build_optimizer`` (optim/adamw.py:16-46).  State is not carried over: call it before the first step (or load a checkpoint after)."""
+        if any(g.get("amsgrad", False) for g in optimizer.param_groups):
+            raise NotImplementedError("amsgrad is not on the HIP hot path")
+        groups = [{k: v for k, v in g.items()} for g in optimizer.param_groups]
+        g0 = groups[0]
+        new = cls(groups, lr=g0["lr"], betas=tuple(g0["betas"]), eps=g0["eps"], weight_decay=g0["weight_decay"])
+        if flat_grads:
+            new.adopt_flat_grads()
+        return new
+
+    def adopt_flat_grads(self) -> None:
+        """Point every parameter's ``.grad`` into ONE flat fp32 buffer that this optimizer owns (parameters whose gradient already is a view
+        of somebody's flat storage — cvnets_amd.ddp's buckets — are left alone).  ``zero_grad`` then is one memset whatever ``set_to_none``
+        says, the gradient addresses never move (the one-launch plan stays valid), and with ``ops.set_inplace_param_grads(True)`` the
+        backward kernels add straight into the buffer: no per-parameter AccumulateGrad work."""
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad and p.grad is None and p.is_cuda and p.dtype == torch.float32]
+        if not ps:
+            return
+        total = sum((p.numel() + 3) // 4 * 4 for p in ps)
+        flat = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            v = flat[off: off + p.numel()].view_as(p)
+            p.grad = v
+            views.append((p, v))
+            off += (p.numel() + 3) // 4 * 4
+        self._flat = (flat, views)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """torch's contract, except that gradients this optimizer owns are zeroed IN PLACE (engine/training_engine.py:224,307 passes
+        set_to_none=True; dropping them would move every gradient address each iteration)."""
+        if self._flat is None:
+            return super().zero_grad(set_to_none=set_to_none)
+        flat, views = self._flat
+        owned = set()
+        for p, v in views:
+            owned.add(id(p))
+            g = p.grad
+            if g is None or g.data_ptr() != v.data_ptr():  # somebody replaced it (autograd allocates a fresh tensor for a None gradient)
+                p.grad = v
+        flat.zero_()
+        for g in self.param_groups:
+            for p in g["params"]:
+                if id(p) not in owned and p.grad is not None:
+                    if p.grad.grad_fn is not None:
+                        p.grad.detach_()
+                    p.grad.zero_()  # (e.g. views of cvnets_amd.ddp's buckets: stay in place as well)
 
     # -------------------------------------------------------------------------------------------------
     def _build(self):

@@ -260,3 +260,58 @@ def test_boundary_overlap_wrapper_copy_pickle_no_sync_and_root_parameters():
             assert ddp._boundary_seen == seen and ddp.boundary_overlap             # ... and did not touch the live wrapper
     finally:
         dist.destroy_process_group()
+
+
+class _InplaceLinearFn(torch.autograd.Function):
+    """a layer in the style of the HIP ops under ops.set_inplace_param_grads(True): the weight gradient is ADDED into weight.grad by the
+    backward itself and autograd is handed None — no post-accumulate hook ever fires for the parameter"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.detach().t()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        ctx.w.grad.add_(g.t() @ x)
+        return g @ ctx.w.detach(), None
+
+
+class _InplaceNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(32, 16) * 0.1)
+        self.w2 = torch.nn.Parameter(torch.randn(8, 32) * 0.1)
+
+    def forward(self, x):
+        return _InplaceLinearFn.apply(torch.relu(_InplaceLinearFn.apply(x, self.w1)), self.w2)
+
+
+def test_inplace_gradients_still_get_exchanged_at_the_end_of_backward():
+    """the engine-driven path of cvnets_amd/launch.py with the fused optimizer: gradients are added in place, no per-parameter hook fires —
+    the wrapper's forward puts a hook on the OUTPUT that queues `finish`, so every bucket is exchanged at the end of backward"""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    from cvnets_amd import ops
+    from cvnets_amd.ddp import DistributedDataParallel
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", init_method="env://")
+    ops.set_inplace_param_grads(True)
+    try:
+        net = _InplaceNet()
+        ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001, first_bucket_mb=0.0001, force_collectives=True)
+        x = torch.randn(4, 16).requires_grad_(True)
+        ddp.zero_grad()
+        f0, n0 = ddp.finish_count, ddp.late_launches + ddp.early_launches
+        ddp(x).square().mean().backward()
+        # every bucket exactly once — from `finish`, or earlier where this PyTorch fires the accumulate hook for an in-place gradient
+        assert ddp.finish_count == f0 + 1 and ddp.late_launches + ddp.early_launches - n0 == len(ddp.buckets)
+        assert float(net.w1.grad.abs().sum()) > 0 and float(net.w2.grad.abs().sum()) > 0
+        with ddp.no_sync():                                      # accumulation micro-step: nothing queued
+            ddp(x).square().mean().backward()
+        assert ddp.finish_count == f0 + 1
+    finally:
+        ops.set_inplace_param_grads(False)
+        dist.destroy_process_group()

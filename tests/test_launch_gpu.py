@@ -113,3 +113,59 @@ def test_engine_loop_bf16_autocast_scaler_accumulation():
     # losses of the 4 batches: the first two are equal to round-off, the last two come after an update each and drift with it; over ~20
     # runs the largest gap seen was 4.0e-2 (on a loss of 7.5)
     assert all(abs(a - b) < 8e-2 for a, b in zip(out[0][1], out[1][1])), (out[0][1], out[1][1])
+
+
+def test_engine_loop_with_the_launchers_fused_adamw_follows_torch_adamw():
+    """substitution 4 of cvnets_amd/launch.py: the reference's Trainer loop (zero_grad(set_to_none=True), GradScaler, clipping, a scheduler that
+    rewrites the group rates, accumulation) stepping `cvnets_amd.optim.AdamW.from_torch(torch AdamW)` — gradients in one flat buffer the
+    kernels add into, one cvh_adamw_multi launch per update — must follow the same loop with torch.optim.AdamW itself (fp32, two parameter
+    groups with and without weight decay as optim/base_optim builds them)."""
+    import cvnets_amd
+    from cvnets_amd import ops
+    from cvnets_amd.layers import default_opts
+
+    base = _load_swapped("xxs", "xx_small")
+    for m in base.modules():
+        if isinstance(m, cvnets_amd.layers.Dropout):
+            m.p = 0.0
+    crit = cvnets_amd.CrossEntropy(default_opts(**{"loss.classification.cross_entropy.label_smoothing": 0.1}))
+    batches = _batches(4)
+
+    class _Sched:
+        def update_lr(self, optimizer, epoch, curr_iter):
+            for g in optimizer.param_groups:
+                g["lr"] = 1e-3 * (0.7 ** curr_iter)
+            return optimizer
+
+    def groups(model):
+        decay = [p for p in model.parameters() if p.dim() > 1]
+        no_decay = [p for p in model.parameters() if p.dim() <= 1]
+        return [{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}]
+
+    cvnets_amd.set_compute_dtype(torch.float32)
+    res = []
+    try:
+        for fused in (False, True):
+            model = copy.deepcopy(base)
+            opt = torch.optim.AdamW(groups(model), lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+            if fused:
+                opt = cvnets_amd.optim.AdamW.from_torch(opt, flat_grads=True)
+                ops.set_inplace_param_grads(True)
+                assert all(p.grad is not None for p in model.parameters())
+                ptrs = [p.grad.data_ptr() for p in model.parameters()]
+            scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=128.0)
+            n, losses = engine_loop.train_iterations(model, crit, opt, _Sched(), scaler, batches, device="cuda:0", accum_freq=2, max_norm=5.0)
+            assert n == 2
+            if fused:
+                assert ptrs == [p.grad.data_ptr() for p in model.parameters()]     # zero_grad(set_to_none=True) did not move a gradient
+                assert opt._rebuilds == 0                                          # ... so the one-launch plan was built once
+                assert set(opt.state_dict()["state"].keys()) == set(range(len(ptrs)))
+            res.append(([p.detach().float().cpu().clone() for p in model.parameters()], losses))
+    finally:
+        ops.set_inplace_param_grads(False)
+        cvnets_amd.set_compute_dtype(None)
+    p0 = [p.detach().float().cpu() for p in base.parameters()]
+    num = sum(float(((a - c) - (b - c)).double().pow(2).sum()) for a, b, c in zip(res[0][0], res[1][0], p0))
+    den = sum(float((a - c).double().pow(2).sum()) for a, c in zip(res[0][0], p0))
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5     # AdamW normalises each gradient: compare the accumulated update
+    assert all(abs(a - b) < 2e-3 for a, b in zip(res[0][1], res[1][1])), (res[0][1], res[1][1])

@@ -22,6 +22,8 @@ from util import l2_err
 
 pytestmark = pytest.mark.gpu
 BF16_SLACK = 1.5
+BF16_GRAD_NORM_BOUND = {"mobilevit_xxs_32_b8": 0.37, "mobilevit_s_128_b2": 0.27, "mobilevit_s_256_b2": 0.27, "mobilevit_s_160_b2": 0.26,
+                        "mobilevit_xxs_128_b2": 0.36}
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = [("mobilevit_xxs_32_b8", "xx_small", 8, 32), ("mobilevit_s_128_b2", "small", 2, 128), ("mobilevit_s_256_b2", "small", 2, 256),
          ("mobilevit_s_160_b2", "small", 2, 160),
@@ -72,7 +74,9 @@ def test_train_step_vs_reference_golden(name, mode, batch, res, dtype):
     e_eval = l2_err(le, torch.from_numpy(gold["logits_eval"]))
     e_train = l2_err(logits, torch.from_numpy(gold["logits_train"]))
     print(f"[{name} {dtype}] logits rel-L2 eval {e_eval:.2e} train {e_train:.2e} loss {loss:.5f} vs {float(gold['loss']):.5f}")
-    assert e_eval < (1e-4 if fp32 else 3e-2), e_eval
+    # eval mode has no batch statistics to amplify round-off: bf16 measures 3.0e-3 ... 4.4e-3 on these five fixtures (round 5, MI355X);
+    # the bound is 2 x the largest value measured — a wrong rounding point or operand shows up an order of magnitude above it
+    assert e_eval < (1e-4 if fp32 else 8e-3), e_eval
     assert e_train < (1e-4 if fp32 else BF16_SLACK * ref_bf16["logits_train"]), (e_train, ref_bf16)
     assert abs(loss - float(gold["loss"])) < (1e-4 if fp32 else max(2e-2, BF16_SLACK * ref_bf16["loss"]))
     names = [str(n) for n in gold["grad_names"]]
@@ -81,7 +85,10 @@ def test_train_step_vs_reference_golden(name, mode, batch, res, dtype):
     gref = torch.from_numpy(gold["grad_norm"])
     worst = float(((gn - gref).abs() / (gref + 1e-3 * gref.max())).max())
     print(f"[{name} {dtype}] worst per-tensor grad-norm deviation {worst:.2e}")
-    assert worst < (2e-3 if fp32 else BF16_SLACK * ref_bf16["grad_norm_worst"]), (worst, ref_bf16)
+    # bf16: ABSOLUTE bounds (2 x the value measured on MI355X, round 5: 1.87e-1 / 1.34e-1 / 1.38e-1 / 1.31e-1 / 1.81e-1 in CASES order —
+    # 2- and 8-image train-mode BatchNorm), and never looser than the reference's own bf16-autocast deviation allows (which on
+    # mobilevit_s_256_b2 would have been 0.89: a bound that catches nothing)
+    assert worst < (2e-3 if fp32 else min(BF16_GRAD_NORM_BOUND[name], BF16_SLACK * ref_bf16["grad_norm_worst"])), (worst, ref_bf16)
     for key in gold.files:
         if key.startswith("grad::"):
             e = l2_err(grads[key[6:]], torch.from_numpy(gold[key]))

@@ -25,6 +25,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + CSRC, "-I
 # MobileViT / ViT training step (reproducibility): the token-embedding gradient of CLIP (tokens.hip), the token-axis
 # LayerNorm quirk branch (layernorm.hip), the scratch-less dW mode nothing calls (gemm_tn.hpp, included by gemm.hip)
 UNSAFE_FP_ATOMICS = {"tokens.hip", "layernorm.hip", "gemm.hip"}
+# non-temporal 16-byte global LOADS (common.hpp: CVH_NT_LOADS) for the two files whose kernels are pure streams over tensors far larger than
+# the caches (BatchNorm apply / backward / column reductions, dropout, LayerNorm): -0.5 ms per step same box (69.8 vs 70.3, twice).  The same
+# hint on the operand loads of gemm_stream_kernel costs +1.7 ms (its 16-byte row pieces share cache lines: they need the L1) and +0.3 ms on the
+# ir_* streaming kernels — measured in round 5 (gpurun_out/r05g), left off there (CVH_NT_STREAM).
+NT_LOADS = {"elementwise.hip", "layernorm.hip"}
 
 
 def hipcc():
@@ -47,7 +52,7 @@ def compile_one(src, force, verbose):
     if not force and not _stale(obj, deps):
         return obj, 0.0, ""
     t0 = time.time()
-    cmd = [hipcc()] + FLAGS + (["-munsafe-fp-atomics"] if src in UNSAFE_FP_ATOMICS else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [hipcc()] + FLAGS + (["-munsafe-fp-atomics"] if src in UNSAFE_FP_ATOMICS else []) + (["-DCVH_NT_LOADS"] if src in NT_LOADS else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

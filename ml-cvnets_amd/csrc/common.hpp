@@ -76,8 +76,61 @@ template <> __device__ __forceinline__ V8<float> v8_zero<float>() {
   r.b = r.a;
   return r;
 }
-template <typename T> __device__ __forceinline__ V8<T> v8_load(const T* p) { return *reinterpret_cast<const V8<T>*>(p); }
-template <typename T> __device__ __forceinline__ void v8_store(T* p, const V8<T>& v) { *reinterpret_cast<V8<T>*>(p) = v; }
+// CVH_NT_LOADS / CVH_NT_STORES (compile-time, per translation unit: tools/build_variant.py): non-temporal 16-byte global accesses for the
+// kernels that stream tensors far larger than the caches exactly once
+typedef unsigned int cvh_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16(const void* p) {
+#ifdef CVH_NT_LOADS
+  const cvh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cvh_u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void st16(void* p, uint4 u) {
+#ifdef CVH_NT_STORES
+  cvh_u32x4 v = {u.x, u.y, u.z, u.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<cvh_u32x4*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = u;
+#endif
+}
+// explicit streaming sites (the once-read operand tiles of gemm_stream / ir_pb / ir_exp_bwd / ir_red_fwd): CVH_NT_STREAM / CVH_NT_STREAM_ST
+__device__ __forceinline__ uint4 ld16_stream(const void* p) {
+#ifdef CVH_NT_STREAM
+  const cvh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cvh_u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void st16_stream(void* p, uint4 u) {
+#ifdef CVH_NT_STREAM_ST
+  cvh_u32x4 v = {u.x, u.y, u.z, u.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<cvh_u32x4*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = u;
+#endif
+}
+template <typename T> __device__ __forceinline__ V8<T> v8_load(const T* p);
+template <> __device__ __forceinline__ V8<bf16_t> v8_load<bf16_t>(const bf16_t* p) {
+  V8<bf16_t> r;
+  r.d = ld16(p);
+  return r;
+}
+template <> __device__ __forceinline__ V8<float> v8_load<float>(const float* p) {
+  V8<float> r;
+  const uint4 a = ld16(p), b = ld16(p + 4);
+  r.a = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+  r.b = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+  return r;
+}
+template <typename T> __device__ __forceinline__ void v8_store(T* p, const V8<T>& v);
+template <> __device__ __forceinline__ void v8_store<bf16_t>(bf16_t* p, const V8<bf16_t>& v) { st16(p, v.d); }
+template <> __device__ __forceinline__ void v8_store<float>(float* p, const V8<float>& v) {
+  st16(p, make_uint4(__float_as_uint(v.a.x), __float_as_uint(v.a.y), __float_as_uint(v.a.z), __float_as_uint(v.a.w)));
+  st16(p + 4, make_uint4(__float_as_uint(v.b.x), __float_as_uint(v.b.y), __float_as_uint(v.b.z), __float_as_uint(v.b.w)));
+}
 // branch-free predicated load, in two halves so that the load stays a PREFETCH: v8_load_clamped reads base[ok ? off : 0 ...] (always
 // a valid address) and returns whatever is there; v8_mask zeroes it where the value is CONSUMED.  (Conditional per-element loads of
 // several register arrays in one loop make the optimizer sink them behind pointer phis, which pins the arrays in scratch memory;

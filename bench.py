@@ -467,6 +467,8 @@ def run(args):
         headline = args.mode == "small" and args.res == 256 and args.dtype == "bf16"
         out["config"].update({"hipgraph": graph is not None, "dropout": 0.1, "loss": round(loss_val, 4),
                               "allreduce": ("in-graph (RCCL, side stream)" if graph_has_allreduce else "after replay (RCCL, side stream)") if multi else None,
+                              "communicator": (("cvh_comm (own RCCL communicator, cvnets_amd/comm.py)" if ddp.comm is not None else "torch.distributed (fall-back)")
+                                               if multi else None),
                               "allreduce_buckets": ddp.overlap_report()["bucket_mb"] if multi else None,
                               "allreduce_buckets_started_inside_backward": graph_overlapped if (multi and graph_has_allreduce) else None,
                               "step": "zero_grad+fwd+CE(ls=0.1)+bwd" + ("+allreduce" if multi else "") +
@@ -538,6 +540,9 @@ def run(args):
                 out["cpu_baseline"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if multi:
+        from cvnets_amd import comm as hip_comm
+        torch.cuda.synchronize()
+        hip_comm.destroy_default()
         dist.destroy_process_group()
 
 

@@ -77,12 +77,20 @@ class Communicator:
     def from_store(cls, store, world: int, rank: int, device=None, key: str = "cvnets_amd/comm/0") -> "Communicator":
         """utils/ddp_utils.py:63-89 without a torch process group on the data path: `store` is any torch.distributed.Store (the TCP store
         the env:// rendezvous opened, or one created for the purpose); rank 0 publishes the unique id under `key`, the others block on it."""
+        return cls(world, rank, cls.exchange_unique_id(store, rank, key), device)
+
+    @classmethod
+    def exchange_unique_id(cls, store, rank: int, key: str = "cvnets_amd/comm/0") -> bytes:
+        """the rendezvous half of `from_store` (host only: tests/test_ddp_cpu.py runs it on two gloo ranks): rank 0 draws the id and publishes
+        it, every other rank blocks on the key (the store's own timeout applies)"""
         if rank == 0:
             uid = cls.new_unique_id()
             store.set(key, uid)
         else:
             uid = bytes(store.get(key))
-        return cls(world, rank, uid, device)
+        if len(uid) != _ID_BYTES:
+            raise RuntimeError(f"rendezvous key {key!r} holds {len(uid)} bytes, not an RCCL unique id")
+        return uid
 
     @classmethod
     def single(cls, device=None) -> "Communicator":
@@ -182,6 +190,9 @@ def init_default(device=None, store=None, world: Optional[int] = None, rank: Opt
             world, rank = dist.get_world_size(), dist.get_rank()
         else:
             world, rank = 1, 0
+    import sys
+
+    c = None
     try:
         if world == 1:
             c = Communicator.single(dev)
@@ -193,11 +204,22 @@ def init_default(device=None, store=None, world: Optional[int] = None, rank: Opt
             c = Communicator.from_store(store, world, rank, dev, key=f"cvnets_amd/comm/{_generation}")
         c.self_test()
     except Exception as e:  # never silent: the run goes on over torch.distributed, and says so
-        import sys
-
         sys.stderr.write(f"[cvnets_amd.comm] own RCCL communicator unavailable ({type(e).__name__}: {e}); falling back to torch.distributed\n")
-        return None
+        if c is not None:
+            try:
+                c.destroy()
+            except Exception:
+                pass
+        c = None
     _generation += 1
+    if world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == world:
+        # the decision is COLLECTIVE: a communicator that came up on some ranks only would leave the ranks on different data planes
+        ok = torch.tensor([1 if c is not None else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and c is not None:
+            sys.stderr.write("[cvnets_amd.comm] another rank could not bring its communicator up; every rank falls back to torch.distributed\n")
+            c.destroy()
+            c = None
     _default = c
     return c
 

@@ -132,3 +132,43 @@ def test_channels_last_model_with_contiguous_input_takes_a_correct_stem_path():
     (l0, g0), (l1, g1) = outs
     assert float((l0 - l1).norm() / l0.norm()) < 5e-2  # two bf16 realisations of the same network (different stem kernels)
     assert float((g0 - g1).norm() / g0.norm()) < 2.5e-1
+
+
+def test_stem_layer_both_weight_layouts_against_fp32_reference():
+    """the model-level comparison above tolerates 5e-2 / 2.5e-1 (two bf16 realisations of a network with train-mode
+    BatchNorm over 4 images), which would not catch a wrong tap or channel permutation in the fall-back path.  The stem LAYER alone —
+    conv_1 = 3x3 stride-2 conv + train-mode BatchNorm + SiLU on the NCHW image — with a contiguous weight (stem kernels) and with a
+    channels_last weight (repack + implicit-GEMM path), each against an fp32 torch evaluation of the layer on the same bf16-rounded
+    operands: output 1e-2, weight gradient 3e-2 (the usual per-kernel bf16 bounds)."""
+    import torch.nn.functional as F
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+    from oracle.weights import seeded_input, seeded_state_dict
+    opts = default_opts(**{"model.classification.mit.mode": "xx_small"})
+    x = seeded_input((4, 3, 64, 64), seed=3).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    cvnets_amd.set_compute_dtype(torch.bfloat16)
+    try:
+        for cl in (False, True):
+            m = cvnets_amd.MobileViT(opts)
+            m.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0))
+            m = m.cuda().train()
+            if cl:
+                m = m.to(memory_format=torch.channels_last)
+            layer = m.conv_1
+            w, gam, bet = layer.block.conv.weight, layer.block.norm.weight, layer.block.norm.bias
+            y = layer(x)
+            go = torch.randn(y.shape, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            y.backward(go)
+            torch.cuda.synchronize()
+            # fp32 reference on the operands as the kernels see them (image and weight rounded to bf16, raw conv output stored as bf16)
+            wr = w.detach().to(torch.bfloat16).float().contiguous().requires_grad_(True)
+            c = F.conv2d(x.to(torch.bfloat16).float(), wr, stride=2, padding=1)
+            c = c + (c.to(torch.bfloat16).float() - c).detach()
+            ref = F.silu(F.batch_norm(c, None, None, gam.detach().float(), bet.detach().float(), training=True, eps=layer.block.norm.eps))
+            ref.backward(go.float())
+            e_y = float((y.detach().float() - ref.detach()).abs().max() / ref.detach().abs().max())
+            e_w = float((w.grad.detach().float().contiguous() - wr.grad).norm() / wr.grad.norm())
+            assert e_y < 1e-2 and e_w < 3e-2, (cl, e_y, e_w)
+    finally:
+        cvnets_amd.set_compute_dtype(None)

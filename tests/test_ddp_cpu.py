@@ -315,3 +315,39 @@ def test_inplace_gradients_still_get_exchanged_at_the_end_of_backward():
     finally:
         ops.set_inplace_param_grads(False)
         dist.destroy_process_group()
+
+
+def _uid_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cvnets_amd import comm
+    from cvnets_amd.ddp import distributed_init
+
+    assert distributed_init("gloo", torch.device("cpu")) == rank
+    assert comm.default() is None and comm.init_default(torch.device("cpu")) is None   # CPU ranks stay on torch.distributed (gloo)
+    store = dist.distributed_c10d._get_default_store()
+    uid = comm.Communicator.exchange_unique_id(store, rank, key="cvnets_amd/comm/test")
+    q.put((rank, uid))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unique_id_rendezvous_through_the_tcp_store_world2():
+    """the host half of the own-communicator bring-up (utils/ddp_utils.py:63-89 rewired): rank 0 draws the RCCL unique id (ncclGetUniqueId
+    needs no GPU), the TCP store of the env:// rendezvous carries its 128 bytes, every rank ends up with the same id.  ncclCommInitRank and
+    the collectives themselves need GPUs: tests/test_rccl_gpu.py (one GPU, world of one); N > 1 runs are the driver's."""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    from cvnets_amd import comm
+    if not comm.available():
+        pytest.skip("librccl not installed on this box")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_uid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(got[0]) == 128 and got[0] == got[1] and any(got[0])

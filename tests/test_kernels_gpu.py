@@ -64,8 +64,9 @@ LINEAR_SHAPES = [(128, 16, 64), (1000, 64, 32), (257, 144, 432), (4096, 288, 144
                  (77, 32, 128), (20000, 32, 128), (130, 384, 192),
                  # transformer-sized linears: bf16 takes the 128x128 direct-to-LDS kernel (csrc/gemm_big.hip) for fwd AND dX
                  (2500, 768, 768), (2048, 256, 1024), (4100, 3072, 768), (3000, 512, 2304),
-                 # M >= 8192, N % 256 == 0: the 256 x 256 four-stage kernel (gemm_nt256_kernel), rows not a multiple of the tile
-                 (33000, 768, 3072), (87000, 3072, 768), (40000, 512, 2048), (131072 + 5, 64, 512)]
+                 # N % 256 == 0, K % 64 == 0 (K > 64) and >= 1024 tiles of 256 x 256 (csrc/gemm_big.hip gemm_big_eligible): gemm_nt256_kernel,
+                 # rows not a multiple of the tile — 129 x 12, 344 x 3, 157 x 8, 547 x 2 tiles
+                 (33000, 768, 3072), (88000, 3072, 768), (40000, 512, 2048), (140000 + 5, 128, 512)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

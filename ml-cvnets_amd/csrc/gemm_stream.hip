@@ -44,7 +44,7 @@ template <int FW, int NKMAX, int EM = 0>
 __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmParams p, GemmStreamGeom g) {
   constexpr int CW = 16 * FW;           // chunk width
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int PK = g.Kp + 8;              // weight pitch: (Kp / 8) is even, +1 chunk makes the 16 rows of a ds_read_b128 group hit 16 distinct bank quads
+  const int PK = g.Kp + CVH_M16_PAD;    // weight pitch: Kp / 8 is a multiple of 4, + 2 chunks = 2 (mod 4): conflict-free fragment reads (common.hpp)
   const int SP = g.bn + 8;              // staging pitch (elements): rows stay 16-byte aligned
   bf16_t* Ws = reinterpret_cast<bf16_t*>(smem_raw);                       // [bn][PK]
   float* bias_s = reinterpret_cast<float*>(Ws + (size_t)g.bn * PK);       // [bn]
@@ -263,7 +263,7 @@ static bool gemm_stream_geom(const ConvGemmParams& p, int em, GemmStreamGeom& g,
   if (fw == 0) return false;
   const int cw = 16 * fw;
   g.Kp = (K + 31) / 32 * 32;
-  const int pk = g.Kp + 8;
+  const int pk = g.Kp + CVH_M16_PAD;
   auto bytes = [&](int bn) { return (size_t)bn * pk * 2 + (size_t)bn * 4 * (1 + (em ? 2 : 0) + (em == 2 ? 4 : 0)) + (size_t)GS_WAVES * GS_MT * (bn + 8) * 2; };
   // widest column tile (a multiple of the chunk width that divides N) whose weights + staging fit the 160 KB of a CU
   int best = 0;

@@ -44,8 +44,8 @@ template <int HBK, int CB>
 __global__ __launch_bounds__(IB_THREADS) void ir_exp_bwd_kernel(IrExpBwdParams p) {
   constexpr int HID = 16 * HBK, CIN = 16 * CB, HPW = (HBK + 7) / 8;
   constexpr int XK = (CIN + 31) / 32 * 32;          // x part of the contraction, whole 32-wide steps (columns >= CIN are zero)
-  constexpr int WP = HID + XK + 8;                   // pitches (elements): + 16 bytes keeps ds_read_b128 groups off the same banks
-  constexpr int GP = HID + 8, XP = XK + 8;
+  constexpr int WP = HID + XK + CVH_M16_PAD;         // pitches (elements): whole 64-byte K steps + 2 chunks: conflict-free fragment reads (common.hpp)
+  constexpr int GP = HID + CVH_M16_PAD, XP = XK + CVH_M16_PAD;
   constexpr int TILE = IB_TM * GP + IB_TM * XP;      // elements of one (g, x) tile pair
   constexpr int GIT = IB_TM * (HID / 8) / IB_THREADS;  // 16-byte g chunks per thread and tile
   constexpr int NBLK = (4 * CB + 7) / 8;             // dX output blocks (16 rows x 16 channels) per wave
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(IB_THREADS) void ir_exp_bwd_kernel(IrExpBwdParams p
 
 template <int HBK, int CB> size_t ir_exp_smem() {
   constexpr int HID = 16 * HBK, CIN = 16 * CB, XK = (CIN + 31) / 32 * 32;
-  return ((size_t)CIN * (HID + XK + 8) + 2 * ((size_t)IB_TM * (HID + 8) + (size_t)IB_TM * (XK + 8))) * 2 + (size_t)CIN * 4;
+  return ((size_t)CIN * (HID + XK + CVH_M16_PAD) + 2 * ((size_t)IB_TM * (HID + CVH_M16_PAD) + (size_t)IB_TM * (XK + CVH_M16_PAD))) * 2 + (size_t)CIN * 4;
 }
 
 bool ir_exp_shape(int hid, int Cin) { return (hid == 64 && Cin == 16) || (hid == 128 && Cin == 32) || (hid == 256 && Cin == 64); }

@@ -34,7 +34,7 @@ struct IrRedFwdParams {
 template <int HBK, int NB>
 __global__ __launch_bounds__(IF_THREADS) void ir_red_fwd_kernel(IrRedFwdParams p) {
   constexpr int HID = 16 * HBK, N = 16 * NB;
-  constexpr int WP = HID + 8, AP = HID + 8;       // pitches (elements): + 16 bytes keeps ds_read_b128 groups off the same banks
+  constexpr int WP = HID + CVH_M16_PAD, AP = HID + CVH_M16_PAD;  // pitches (elements): HID / 8 = 0 (mod 4), + 2 chunks: conflict-free fragment reads (common.hpp)
   constexpr int TILE = IF_TM * AP;
   constexpr int GIT = IF_TM * (HID / 8) / IF_THREADS;
   constexpr int NBLK = (4 * NB + 7) / 8;          // output blocks (16 rows x 16 channels) per wave; they share their 16 rows
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(IF_THREADS) void ir_red_fwd_kernel(IrRedFwdParams p
 
 template <int HBK, int NB> size_t ir_red_fwd_smem() {
   constexpr int HID = 16 * HBK, N = 16 * NB;
-  return ((size_t)N * (HID + 8) + 2 * (size_t)IF_TM * (HID + 8)) * 2 + (size_t)(2 * HID + 2 * N) * 4;
+  return ((size_t)N * (HID + CVH_M16_PAD) + 2 * (size_t)IF_TM * (HID + CVH_M16_PAD)) * 2 + (size_t)(2 * HID + 2 * N) * 4;
 }
 
 bool ir_red_shape(int hid, int N) { return (hid == 64 && N == 32) || (hid == 128 && N == 64) || (hid == 256 && (N == 64 || N == 96)); }

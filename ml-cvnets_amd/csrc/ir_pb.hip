@@ -51,7 +51,7 @@ struct IrPbParams {
 
 template <int NA>  // Cout = 16 NA, NA even
 __global__ __launch_bounds__(256, NA <= 4 ? 3 : 2) void ir_pb_kernel(IrPbParams p) {
-  constexpr int COUT = 16 * NA, KS3 = NA / 2, DP = COUT + 8, DC = COUT / 8;
+  constexpr int COUT = 16 * NA, KS3 = NA / 2, DP = COUT + CVH_M16_PAD, DC = COUT / 8;  // DP: NA even -> COUT / 8 = 0 (mod 4), + 2 chunks (common.hpp)
   constexpr int NYL = PB_TP * 8 / 256, NDL = (PB_TP * DC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* yt = reinterpret_cast<bf16_t*>(smem_raw);      // [64][PB_YP]  y2 tile, this workgroup's 64 channels; g2 after the first phase
@@ -246,7 +246,7 @@ int ir_pb_plan(int M, int hid, int* chunks, int* ntiles) {
   return R;
 }
 
-template <int NA> size_t ir_pb_smem() { return (size_t)PB_TP * (2 * PB_YP + 16 * NA + 8) * 2 + 3 * 16 * NA * 4; }
+template <int NA> size_t ir_pb_smem() { return (size_t)PB_TP * (2 * PB_YP + 16 * NA + CVH_M16_PAD) * 2 + 3 * 16 * NA * 4; }
 
 }  // namespace
 

@@ -599,10 +599,12 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, x_q: Tensor, x_kv: Optional[Tensor] = None, key_padding_mask: Optional[Tensor] = None,
                 attn_mask: Optional[Tensor] = None, *args, **kwargs) -> Tensor:
-        if x_kv is not None:
-            raise NotImplementedError("cross-attention is not on the HIP hot path")
         if self.coreml_compatible:
-            raise NotImplementedError("the forward_tracing variant is not on the HIP hot path")
+            # forward_tracing (multi_head_attention.py:81-133) is the same product written head by head for export, WITHOUT the two masks
+            # (it never reads them): the fused kernels compute it; the masks are dropped exactly as the reference's branch drops them
+            key_padding_mask = attn_mask = None
+        if x_kv is not None:
+            return self._forward_cross(x_q, x_kv, key_padding_mask, attn_mask)
         seq_first = bool(kwargs.get("use_pytorch_mha", False))
         if seq_first:
             # forward_pytorch (multi_head_attention.py:241-273): F.multi_head_attention_forward on the SAME weights, input [S, B, C]; the
@@ -619,6 +621,46 @@ class MultiHeadAttention(nn.Module):
         y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask)
         y = y.view(b, s, -1)
         return y.transpose(0, 1) if seq_first else y
+
+
+def _cross_attention(self, x_q: Tensor, x_kv: Tensor, key_padding_mask: Optional[Tensor], attn_mask: Optional[Tensor]) -> Tensor:
+    """Cross-attention (multi_head_attention.py:158-185: query from x_q [N, S, C] with the first C rows of qkv_proj, key / value from x_kv
+    [N, T, C] with the other 2C).  Not a path of any §8 model (the spatio-temporal MobileViT uses it), so it is built from the hot path's
+    pieces rather than given kernels of its own: two projection GEMMs, the packed [q | k | v] matrix the fused attention kernels take
+    (column layout identical to self-attention), both sequences padded to L = max(S, T) with the padded keys marked dead in the key-padding
+    table the kernels already honour; the concatenation / padding copies are torch plumbing and differentiate themselves."""
+    if attn_mask is not None:
+        raise NotImplementedError("an additive attention mask with cross-attention is not on the HIP hot path")
+    b, s_len, c = x_q.shape
+    t_len = x_kv.shape[1]
+    if x_kv.shape[0] != b or x_kv.shape[2] != c:
+        raise AssertionError(f"x_kv must be [{b}, T, {c}]. Got: {list(x_kv.shape)}")
+    dt, d = ops.compute_dtype(), self.embed_dim
+    w, bias = self.qkv_proj.weight, self.qkv_proj.bias
+    q = ops.linear(x_q.reshape(b * s_len, c).to(dt).contiguous(), w[:d], None if bias is None else bias[:d])
+    kv = ops.linear(x_kv.reshape(b * t_len, c).to(dt).contiguous(), w[d:], None if bias is None else bias[d:])
+    L = max(s_len, t_len)
+    q3, kv3 = q.view(b, s_len, d), kv.view(b, t_len, 2 * d)
+    if s_len < L:
+        q3 = torch.nn.functional.pad(q3, (0, 0, 0, L - s_len))
+    kpm = key_padding_mask
+    if kpm is not None and list(kpm.shape) != [b, t_len]:
+        raise AssertionError(f"Key_padding_mask should be 2-dimension with shape [{b}, {t_len}]. Got: {list(kpm.shape)}")
+    if t_len < L:
+        kv3 = torch.nn.functional.pad(kv3, (0, 0, 0, L - t_len))
+        dead = torch.zeros(b, L, dtype=torch.bool, device=x_q.device)
+        dead[:, t_len:] = True
+        if kpm is not None:
+            dead[:, :t_len] = kpm.to(torch.bool)
+        kpm = dead
+    qkv = torch.cat([q3, kv3], dim=-1).reshape(b * L, 3 * d)  # plumbing
+    o = ops.attention(qkv, self.num_heads, (b, L, 1, 1, L, 1, L), causal=False, key_padding_mask=kpm,
+                      drop_p=float(self.attn_dropout.p) if self.training else 0.0)
+    o = o.view(b, L, d)[:, :s_len].reshape(b * s_len, d)
+    return ops.linear(o.contiguous(), self.out_proj.weight, self.out_proj.bias).view(b, s_len, -1)
+
+
+MultiHeadAttention._forward_cross = _cross_attention
 
 
 def _mask_is_causal(attn_mask: Tensor, b: int, s: int, allow_2d: bool = False) -> bool:

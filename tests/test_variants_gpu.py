@@ -92,3 +92,74 @@ def test_transformer_encoder_with_ffn_dropout():
     assert float((y.float() - r).abs().max() / r.abs().max()) < 2e-4
     assert float((gx.float() - rx).abs().max() / rx.abs().max()) < 2e-3
     assert float((y_eval.float() - ref(x.detach(), None)).abs().max() / r.abs().max()) < 2e-4
+
+
+def _mha_reference(m, x_q, x_kv, kpm):
+    """the reference's forward_default written out (cvnets/layers/multi_head_attention.py:135-239), fp32, ATen + autograd"""
+    C, H = m.embed_dim, m.num_heads
+    w, b = m.qkv_proj.weight, m.qkv_proj.bias
+    N, S, _ = x_q.shape
+    T = x_kv.shape[1]
+    q = F.linear(x_q, w[:C], b[:C]).reshape(N, S, H, C // H).transpose(1, 2) * m.scaling
+    kv = F.linear(x_kv, w[C:], b[C:]).reshape(N, T, 2, H, C // H).transpose(1, 3)
+    k, v = kv[:, :, 0], kv[:, :, 1]
+    attn = q @ k.transpose(-1, -2)
+    if kpm is not None:
+        attn = attn.masked_fill(kpm[:, None, None, :].to(torch.bool), float("-inf"))
+    out = (torch.softmax(attn.float(), dim=-1) @ v).transpose(1, 2).reshape(N, S, C)
+    return F.linear(out, m.out_proj.weight, m.out_proj.bias)
+
+
+@pytest.mark.parametrize("S,T,masked", [(24, 24, False), (10, 17, False), (17, 10, True), (32, 5, False)])
+def test_cross_attention_matches_the_reference_formula(S, T, masked):
+    """MultiHeadAttention(x_q, x_kv) (multi_head_attention.py:158-185): query from the first C rows of qkv_proj on x_q [N, S, C], key / value from
+    the other 2C on x_kv [N, T, C], any S and T (padded to max(S, T) with the padded keys dead), with a key-padding mask over T; output and
+    every gradient (both inputs, both projections) against the formula in fp32."""
+    import cvnets_amd
+    torch.manual_seed(11)
+    N, C, H = 3, 64, 4
+    m = cvnets_amd.MultiHeadAttention(C, H).to(DEV).train()
+    xq = torch.randn(N, S, C, device=DEV, requires_grad=True)
+    xk = torch.randn(N, T, C, device=DEV, requires_grad=True)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(N, T, dtype=torch.bool, device=DEV)
+        kpm[0, T - 3:] = True
+        kpm[2, 1] = True
+    go = torch.randn(N, S, C, device=DEV)
+    params = [m.qkv_proj.weight, m.qkv_proj.bias, m.out_proj.weight, m.out_proj.bias]
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        y = m(xq, xk, key_padding_mask=kpm)
+        got = torch.autograd.grad(y, [xq, xk] + params, go)
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    ref = _mha_reference(m, xq, xk, kpm)
+    want = torch.autograd.grad(ref, [xq, xk] + params, go)
+    assert y.shape == ref.shape == (N, S, C)
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 2e-4
+    for name, a, b in zip(["x_q", "x_kv", "qkv.weight", "qkv.bias", "out.weight", "out.bias"], got, want):
+        assert float((a.float() - b).abs().max() / b.abs().max()) < 2e-3, name
+
+
+def test_coreml_compatible_attention_is_the_same_product():
+    """forward_tracing (multi_head_attention.py:81-133) computes the self-attention product head by head and ignores both masks; the layer
+    with coreml_compatible=True must give the default path's unmasked result (and must not raise)."""
+    import cvnets_amd
+    torch.manual_seed(12)
+    N, S, C, H = 2, 21, 64, 4
+    a = cvnets_amd.MultiHeadAttention(C, H).to(DEV).eval()
+    b = cvnets_amd.MultiHeadAttention(C, H, coreml_compatible=True).to(DEV).eval()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(N, S, C, device=DEV)
+    kpm = torch.zeros(N, S, dtype=torch.bool, device=DEV)
+    kpm[0, 10:] = True
+    cvnets_amd.set_compute_dtype(torch.float32)
+    try:
+        with torch.no_grad():
+            ya, yb = a(x), b(x, key_padding_mask=kpm)
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    assert torch.equal(ya, yb)
+    ref = _mha_reference(a, x, x, None)
+    assert float((yb.float() - ref).abs().max() / ref.abs().max()) < 2e-4

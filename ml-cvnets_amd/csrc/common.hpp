@@ -95,23 +95,6 @@ __device__ __forceinline__ void st16(void* p, uint4 u) {
   *reinterpret_cast<uint4*>(p) = u;
 #endif
 }
-// explicit streaming sites (the once-read operand tiles of gemm_stream / ir_pb / ir_exp_bwd / ir_red_fwd): CVH_NT_STREAM / CVH_NT_STREAM_ST
-__device__ __forceinline__ uint4 ld16_stream(const void* p) {
-#ifdef CVH_NT_STREAM
-  const cvh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cvh_u32x4*>(p));
-  return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *reinterpret_cast<const uint4*>(p);
-#endif
-}
-__device__ __forceinline__ void st16_stream(void* p, uint4 u) {
-#ifdef CVH_NT_STREAM_ST
-  cvh_u32x4 v = {u.x, u.y, u.z, u.w};
-  __builtin_nontemporal_store(v, reinterpret_cast<cvh_u32x4*>(p));
-#else
-  *reinterpret_cast<uint4*>(p) = u;
-#endif
-}
 template <typename T> __device__ __forceinline__ V8<T> v8_load(const T* p);
 template <> __device__ __forceinline__ V8<bf16_t> v8_load<bf16_t>(const bf16_t* p) {
   V8<bf16_t> r;

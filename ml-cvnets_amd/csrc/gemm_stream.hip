@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void gemm_stream_kernel(ConvGemmPara
     for (int ks = 0; ks < NKMAX; ++ks) {
       if (ks < nk) {
         const int col = 32 * ks + 8 * l4;
-        a[ks] = __builtin_bit_cast(bf16x8_t, ld16_stream(rp + (col < K ? col : 0)));
+        a[ks] = *reinterpret_cast<const bf16x8_t*>(rp + (col < K ? col : 0));
       }
     }
   };

@@ -74,12 +74,12 @@ __global__ __launch_bounds__(IB_THREADS) void ir_exp_bwd_kernel(IrExpBwdParams p
       const int i = tid + it * IB_THREADS;
       const int r = i / (HID / 8), ck = i - r * (HID / 8);
       gr[it] = make_uint4(0, 0, 0, 0);
-      if (row0 + r < p.M) gr[it] = ld16_stream(p.g + (size_t)(row0 + r) * HID + ck * 8);
+      if (row0 + r < p.M) gr[it] = *reinterpret_cast<const uint4*>(p.g + (size_t)(row0 + r) * HID + ck * 8);
     }
     xr = make_uint4(0, 0, 0, 0);
     if (tid < IB_TM * (CIN / 8)) {
       const int r = tid / (CIN / 8), ck = tid - r * (CIN / 8);
-      if (row0 + r < p.M) xr = ld16_stream(p.x + (size_t)(row0 + r) * CIN + ck * 8);
+      if (row0 + r < p.M) xr = *reinterpret_cast<const uint4*>(p.x + (size_t)(row0 + r) * CIN + ck * 8);
     }
   };
   auto store_tile = [&](bf16_t* gt) __attribute__((always_inline)) {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(IF_THREADS) void ir_red_fwd_kernel(IrRedFwdParams p
       const int i = tid + it * IF_THREADS;
       const int r = i / (HID / 8), ck = i - r * (HID / 8);
       gr[it] = make_uint4(0, 0, 0, 0);
-      if (row0 + r < p.M) gr[it] = ld16_stream(p.y2 + (size_t)(row0 + r) * HID + ck * 8);
+      if (row0 + r < p.M) gr[it] = *reinterpret_cast<const uint4*>(p.y2 + (size_t)(row0 + r) * HID + ck * 8);
     }
   };
   // BatchNorm + activation on the way into LDS (rows past M become act(shift): they are multiplied but never stored or counted)

@@ -103,15 +103,15 @@ __global__ __launch_bounds__(256, NA <= 4 ? 3 : 2) void ir_pb_kernel(IrPbParams 
       const int i = tid + it * 256;
       const int px = i >> 3, cg = i & 7;
       const bool ok = r0 + px < (size_t)p.M && c0 + cg * 8 < hid;
-      yr[it] = ok ? ld16_stream(p.y2 + (r0 + px) * hid + c0 + cg * 8) : make_uint4(0, 0, 0, 0);
+      yr[it] = ok ? *reinterpret_cast<const uint4*>(p.y2 + (r0 + px) * hid + c0 + cg * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < NDL; ++it) {
       const int i = tid + it * 256;
       const int px = i / DC, cg = i - px * DC;
       const bool ok = i < PB_TP * DC && r0 + px < (size_t)p.M;
-      dr[it] = ok ? ld16_stream(p.dy + (r0 + px) * COUT + cg * 8) : make_uint4(0, 0, 0, 0);
-      if (two_src) d2r[it] = ok ? ld16_stream(p.y3 + (r0 + px) * COUT + cg * 8) : make_uint4(0, 0, 0, 0);
+      dr[it] = ok ? *reinterpret_cast<const uint4*>(p.dy + (r0 + px) * COUT + cg * 8) : make_uint4(0, 0, 0, 0);
+      if (two_src) d2r[it] = ok ? *reinterpret_cast<const uint4*>(p.y3 + (r0 + px) * COUT + cg * 8) : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, NA <= 4 ? 3 : 2) void ir_pb_kernel(IrPbParams 
       const int i = tid + it * 256;
       const int px = i >> 3, cg = i & 7;
       if (r0 + px < (size_t)p.M && c0 + cg * 8 < hid)
-        st16_stream(p.g2 + (r0 + px) * hid + c0 + cg * 8, *reinterpret_cast<const uint4*>(yt + px * PB_YP + cg * 8));
+        *reinterpret_cast<uint4*>(p.g2 + (r0 + px) * hid + c0 + cg * 8) = *reinterpret_cast<const uint4*>(yt + px * PB_YP + cg * 8);
     }
   }
 

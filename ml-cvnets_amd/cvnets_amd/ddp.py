@@ -97,6 +97,32 @@ class _BoundaryPreHook:
         return _inert_boundary_hook(self.ci)
 
 
+class _BoundaryEndHook:
+    """forward hook of the root module: the forward is over, its candidate order is known.  Inert on copies, like _BoundaryPreHook."""
+
+    def __init__(self, ddp):
+        import weakref
+        self._ddp = weakref.ref(ddp)
+
+    def __call__(self, mod, args, output):
+        ddp = self._ddp() if self._ddp is not None else None
+        if ddp is not None:
+            ddp._post_forward()
+        return None
+
+    def __reduce__(self):
+        return (_inert_end_hook, ())
+
+    def __deepcopy__(self, memo):
+        return _inert_end_hook()
+
+
+def _inert_end_hook() -> "_BoundaryEndHook":
+    h = _BoundaryEndHook.__new__(_BoundaryEndHook)
+    h._ddp = None
+    return h
+
+
 def _inert_boundary_hook(ci: int) -> "_BoundaryPreHook":
     h = _BoundaryPreHook.__new__(_BoundaryPreHook)
     h._ddp, h.ci = None, ci
@@ -209,7 +235,6 @@ class DistributedDataParallel(nn.Module):
         # the join at `finish` become graph edges (bench.py).
         self.boundary_overlap = False
         self._boundary_buckets = {}
-        self._boundary_seen = -1
         if boundary_overlap:
             self._setup_boundaries()
         self._buf_span = None
@@ -218,47 +243,88 @@ class DistributedDataParallel(nn.Module):
 
     # ---- boundary-driven overlap (in-place parameter gradients / captured steps) ----------------
     def _setup_boundaries(self):
-        children = list(self.module.children())
+        """Boundary candidates = the model's top-level children, a plain container (Sequential / ModuleList) of >= 2 parameterised blocks
+        standing for its blocks (MobileViT: layer_2's three InvertedResiduals; ViT / CLIP towers: the transformer blocks).  Their EXECUTION
+        order is what matters, and it is learnt: every forward records the order in which the candidates run (first guess: registration
+        order — right for MobileViT / MobileViTv2; ViT registers `pos_embed` after the blocks it precedes), a forward that deviates from
+        the known order exchanges its buckets at the end of backward and teaches the new order.  A bucket is tied to the earliest-run
+        candidate that owns one of its parameters; when backward reaches that candidate's input, everything that ran after it has its
+        gradient kernels enqueued (the autograd engine works a device's ready nodes newest-first, so this also holds for the two towers
+        of CLIP) and the bucket's all-reduce forks onto the side stream.  Parameters of the root module (`cls_token`), parameters shared
+        between candidates and candidates that run twice in one forward fall back to the end of backward."""
+        cands = []
+        for ch in self.module.children():
+            subs = list(ch.children()) if isinstance(ch, (nn.Sequential, nn.ModuleList)) else []
+            if sum(1 for m in subs if next(m.parameters(), None) is not None) >= 2:
+                cands.extend(subs)
+            else:
+                cands.append(ch)
         owner = {}
-        for ci, ch in enumerate(children):
-            for p in ch.parameters():
-                if p in owner:  # a parameter shared between top-level children: its gradient is complete only at the earlier one
-                    return
-                owner[p] = ci
-        for b in self.buckets:
-            # a parameter registered directly on the root module (ViT / CLIP: cls_token) can be used anywhere in forward: its gradient is
-            # complete only at the end of backward — the bucket that holds it belongs to no boundary and is launched by `finish`
-            if any(p not in owner for p in b.params):
-                continue
-            ci = min(owner[p] for p in b.params)
-            self._boundary_buckets.setdefault(ci, []).append(b)
-        self._boundary_handles = [ch.register_forward_pre_hook(_BoundaryPreHook(self, ci)) for ci, ch in enumerate(children)]
+        for ci, m in enumerate(cands):
+            for p in m.parameters():
+                owner[p] = ci if p not in owner else -1  # shared between candidates: complete only at the end of backward
+        self._cands = cands
+        self._bucket_owners = [{owner.get(p, -1) for p in b.params} for b in self.buckets]
+        self._seq, self._fid, self._tracking, self._dup = [], 0, False, False
+        self._fwd_ok = {}
+        self._learn_order(tuple(range(len(cands))))
+        self._boundary_handles = [m.register_forward_pre_hook(_BoundaryPreHook(self, ci)) for ci, m in enumerate(cands)]
+        self._boundary_handles.append(self.module.register_forward_pre_hook(_BoundaryPreHook(self, -1)))
+        self._boundary_handles.append(self.module.register_forward_hook(_BoundaryEndHook(self)))
         self.boundary_overlap = True
 
+    def _learn_order(self, order):
+        self._order = tuple(order)
+        rank = {ci: r for r, ci in enumerate(self._order)}
+        self._boundary_buckets = {}
+        for b, owners in zip(self.buckets, self._bucket_owners):
+            if -1 in owners or any(ci not in rank for ci in owners):
+                continue  # launched by `finish`
+            self._boundary_buckets.setdefault(min(owners, key=rank.get), []).append(b)
+
     def _pre_forward(self, ci: int, args):
-        if not self.boundary_overlap or self._in_no_sync:
+        if not self.boundary_overlap:
             return None
-        if ci == 0:
-            self._boundary_seen = 0
-        elif ci < self._boundary_seen:
-            import warnings
-            warnings.warn("cvnets_amd.ddp: top-level children do not run in registration order: boundary overlap disabled")
-            self.boundary_overlap = False
+        if ci < 0:  # the root module starts a forward
+            # (a forward INSIDE a backward pass is a checkpoint recomputation: it neither defines an order nor gets boundaries)
+            self._tracking = not self._in_no_sync and torch._C._current_graph_task_id() < 0
+            if self._tracking:
+                self._fid += 1
+                self._seq, self._dup = [], False
             return None
-        else:
-            self._boundary_seen = ci
-        if ci in self._boundary_buckets and self.active and self.boundary_enabled and torch.is_grad_enabled() and args \
-                and isinstance(args[0], torch.Tensor) and args[0].requires_grad:
-            args[0].register_hook(lambda g, ci=ci: self._boundary(ci))
+        if not self._tracking:
+            return None
+        if ci in self._seq:
+            self._dup = True
+        self._seq.append(ci)
+        n = len(self._seq)
+        if (not self._dup and tuple(self._seq) == self._order[:n] and ci in self._boundary_buckets and self.active and self.boundary_enabled
+                and torch.is_grad_enabled() and args and isinstance(args[0], torch.Tensor) and args[0].requires_grad):
+            args[0].register_hook(lambda g, ci=ci, fid=self._fid: self._boundary(ci, fid))
         return None
+
+    def _post_forward(self):
+        if not (self.boundary_overlap and self._tracking):
+            return
+        self._tracking = False
+        seq = tuple(self._seq)
+        ok = not self._dup and seq == self._order
+        self._fwd_ok = {self._fid: ok}  # only the newest forward can have live boundary hooks worth honouring
+        if not ok and not self._dup and len(set(seq)) == len(seq):
+            self._learn_order(seq)  # this step exchanges at the end of backward; the next one uses the order just seen
+        elif self._dup and not self._warned_dup:
+            self._warned_dup = True
+            import warnings
+            warnings.warn("cvnets_amd.ddp: a boundary module ran twice in one forward: its buckets are exchanged at the end of backward")
 
     boundary_enabled = True
     _in_no_sync = False
+    _warned_dup = False
 
-    def _boundary(self, ci: int):
-        """backward has produced the gradient w.r.t. the input of child `ci`: every parameter of children >= ci has its gradient kernels
-        (or deferred partial sums) enqueued"""
-        if not (self.active and self.boundary_overlap and self.boundary_enabled) or self._in_no_sync:
+    def _boundary(self, ci: int, fid: int):
+        """backward has produced the gradient w.r.t. the input of candidate `ci`: every parameter of the candidates that ran at or after it has
+        its gradient kernels (or deferred partial sums) enqueued"""
+        if not (self.active and self.boundary_overlap and self.boundary_enabled) or self._in_no_sync or not self._fwd_ok.get(fid, False):
             return None  # (no_sync: the micro-steps of a gradient accumulation exchange nothing — torch DDP's contract)
         tid = torch._C._current_graph_task_id()
         if self._callback_task != tid:
@@ -267,8 +333,8 @@ class DistributedDataParallel(nn.Module):
             self._callback_task = tid
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
         from . import ops
-        ops.flush_deferred_reductions()  # the partial sums queued so far all belong to children >= ci
-        for b in self._boundary_buckets[ci]:
+        ops.flush_deferred_reductions()  # the partial sums queued so far all belong to candidates that ran at or after this one
+        for b in self._boundary_buckets.get(ci, ()):
             if b.work is None:
                 self.early_launches += 1
                 self._launch(b)
@@ -390,7 +456,7 @@ class DistributedDataParallel(nn.Module):
         new._callback_task, new.hooks_enabled = None, False
         new.early_launches = new.late_launches = new.finish_count = 0
         new._warned_no_overlap = True
-        new.boundary_overlap, new._boundary_buckets, new._boundary_seen = False, {}, -1
+        new.boundary_overlap, new._boundary_buckets = False, {}
         new.training = self.training
         return new
 

@@ -253,11 +253,11 @@ def test_boundary_overlap_wrapper_copy_pickle_no_sync_and_root_parameters():
         for p, w in zip(net.parameters(), want):
             assert torch.allclose(p.grad, 2 * w)
         # (a) copies
-        seen = ddp._boundary_seen
+        seen = (ddp._fid, ddp._order)
         for c in (copy.deepcopy(ddp), pickle.loads(pickle.dumps(ddp))):
             assert not c.active and not c.boundary_overlap
             c(torch.randn(2, 16))                                                   # the copy's (inert) hooks run
-            assert ddp._boundary_seen == seen and ddp.boundary_overlap             # ... and did not touch the live wrapper
+            assert (ddp._fid, ddp._order) == seen and ddp.boundary_overlap           # ... and did not touch the live wrapper
     finally:
         dist.destroy_process_group()
 
@@ -351,3 +351,61 @@ def test_unique_id_rendezvous_through_the_tcp_store_world2():
         p.join(60)
         assert p.exitcode == 0
     assert len(got[0]) == 128 and got[0] == got[1] and any(got[0])
+
+
+class _OutOfOrderNet(torch.nn.Module):
+    """children registered a, norm, blocks, head, pos — executed a, pos, blocks (a container of three blocks), norm, head: the shape of the
+    reference's VisionTransformer (patch_emb, post_transformer_norm, transformer, classifier, pos_embed + a root-level cls_token)"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(16, 32)
+        self.norm = torch.nn.LayerNorm(32)
+        self.blocks = torch.nn.Sequential(torch.nn.Linear(32, 32), torch.nn.Linear(32, 32), torch.nn.Linear(32, 32))
+        self.head = torch.nn.Linear(32, 8)
+        self.pos = torch.nn.Linear(32, 32)
+        self.cls_token = torch.nn.Parameter(torch.zeros(1, 32))
+
+    def forward(self, x):
+        x = self.pos(self.a(x)) + self.cls_token
+        return self.head(self.norm(self.blocks(x)))
+
+
+def test_boundary_overlap_learns_the_execution_order():
+    """ddp.py round 5: the boundary candidates' EXECUTION order is learnt (first guess: registration order).  A model whose children run in
+    another order (ViT: `pos_embed` is registered after the blocks it precedes) exchanges at the end of backward on its first step and
+    overlaps from the second one on, with the blocks of a Sequential container as boundaries of their own; gradients equal the plain
+    backward's in both steps; a checkpoint-style forward inside backward does not disturb the learnt order."""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    from cvnets_amd.ddp import DistributedDataParallel
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", init_method="env://")
+    try:
+        torch.manual_seed(0)
+        net = _OutOfOrderNet()
+        x = torch.randn(4, 16).requires_grad_(True)
+        net(x).square().mean().backward()
+        want = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad()
+        ddp = DistributedDataParallel(net, bucket_cap_mb=0.0001, first_bucket_mb=0.0001, boundary_overlap=True, force_collectives=True)
+        ddp.hooks_enabled = False   # the in-place-gradient regime: boundaries are the only driver besides `finish`
+        assert ddp.boundary_overlap and len(ddp._cands) == 7   # a, norm, blocks.0-2, head, pos
+        reg_order = ddp._order
+        steps = []
+        for _ in range(3):
+            ddp.zero_grad()
+            e0, l0, f0 = ddp.early_launches, ddp.late_launches, ddp.finish_count
+            ddp(x).square().mean().backward()
+            if ddp.finish_count == f0:     # no boundary fired (the first step, on the wrong guess): exchange explicitly, as bench.py does
+                ddp.allreduce_flat()
+            steps.append((ddp.early_launches - e0, ddp.late_launches - l0))
+            for p, w in zip(net.parameters(), want):
+                assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7)
+        assert ddp._order == (0, 6, 2, 3, 4, 1, 5) and ddp._order != reg_order          # a, pos, blocks.0-2, norm, head
+        assert steps[0] == (0, 0) and steps[1][0] >= 3 and steps[2] == steps[1], steps   # first step (wrong guess): no boundary; then overlapped
+        assert all(e + l == len(ddp.buckets) for e, l in steps[1:]), (steps, len(ddp.buckets))
+        # the bucket of the root-level parameter never belongs to a boundary
+        assert all(ddp._bucket_of[net.cls_token] not in lst for lst in ddp._boundary_buckets.values())
+    finally:
+        dist.destroy_process_group()

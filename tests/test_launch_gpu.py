@@ -169,3 +169,43 @@ def test_engine_loop_with_the_launchers_fused_adamw_follows_torch_adamw():
     den = sum(float((a - c).double().pow(2).sum()) for a, c in zip(res[0][0], p0))
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5     # AdamW normalises each gradient: compare the accumulated update
     assert all(abs(a - b) < 2e-3 for a, b in zip(res[0][1], res[1][1])), (res[0][1], res[1][1])
+
+
+def test_engine_loop_under_the_reference_default_float16_autocast():
+    """the shipped YAMLs leave `common.mixed_precision_dtype` at float16 (options/opts.py:126-131): the engine then wraps the step in
+    torch.autocast(float16) with a GradScaler at its default scale (65536).  There are no float16 kernels on this path — such regions are
+    computed in bfloat16 storage / fp32 accumulation, said once in a warning — so the reference configs run unmodified: same trajectory as
+    the bfloat16 run up to the scale handling, finite gradients, the scaler's scale untouched."""
+    import warnings
+    import cvnets_amd
+    from cvnets_amd import ops
+    from cvnets_amd.layers import default_opts
+
+    base = _load_swapped("xxs", "xx_small")
+    for m in base.modules():
+        if isinstance(m, cvnets_amd.layers.Dropout):
+            m.p = 0.0
+    crit = cvnets_amd.CrossEntropy(default_opts(**{"loss.classification.cross_entropy.label_smoothing": 0.1}))
+    batches = _batches(2)
+    res = {}
+    ops._WARNED_FP16 = False
+    for dt in (torch.bfloat16, torch.float16):
+        model = copy.deepcopy(base)
+        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+        scaler = torch.amp.GradScaler("cuda", enabled=True)   # default init_scale 65536, as main_train.py:114 constructs it
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            n, losses = engine_loop.train_iterations(model, crit, opt, _ConstLR(), scaler, batches, device="cuda:0", amp_dtype=dt)
+        assert n == 2 and scaler.get_scale() == 65536.0 and all(l == l for l in losses)
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+        said = [x for x in w if "float16 autocast regions are computed in bfloat16" in str(x.message)]
+        assert (len(said) == 1) == (dt == torch.float16), [str(x.message) for x in w]
+        res[dt] = losses
+    # both runs compute in bf16: identical kernels, identical losses
+    assert res[torch.float16] == res[torch.bfloat16], res
+    os.environ["CVH_STRICT_AUTOCAST"] = "1"
+    try:
+        with pytest.raises(RuntimeError), torch.autocast("cuda", dtype=torch.float16):
+            ops.compute_dtype()
+    finally:
+        os.environ.pop("CVH_STRICT_AUTOCAST", None)

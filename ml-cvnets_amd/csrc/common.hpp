@@ -428,6 +428,7 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_NO_CONV3X3 14 /* 1: dense 3x3 convolutions stay on the im2col conv_gemm_kernel instead of conv3x3_kernel */
 #define CVH_TUNE_NO_CONV3X3_DW 15 /* 1: the weight gradient of those convolutions stays on the im2col gemm_tn_kernel instead of conv3x3_dw_kernel */
 #define CVH_TUNE_BIG_MIN_N 16 /* narrowest output the ragged direct-to-LDS GEMM takes (0: the default, 192) */
+#define CVH_TUNE_NO_TN256 19 /* 1: the direct-to-LDS dW product stays on 128 x 128 tiles (gemm_big.hip: gemm_tn256_shape) */
 #define CVH_TUNE_GEMM_FILL 18 /* conv_gemm: narrow the N tile until the launch has at least this many workgroups (0: off) */
 #define CVH_TUNE_MAX 24
 int cvh_tune_get(int key);

@@ -185,21 +185,25 @@ static bool tn_skinny_shape(int M, int N, int Ktot) {
 }
 
 static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* splits, int* mps) {
-  const int n_tiles = (N + 127) / 128;
-  *k_tiles = (Ktot + 127) / 128;
+  // the direct-to-LDS kernel's tile: 256 x 256 where that moves fewer operand columns per row (gemm_big.hip: gemm_tn256_shape), else 128 x 128
+  const bool t256 = tn_big_shape(M, N, Ktot) && cvh_tune_get(CVH_TUNE_BIG_GEMM) && gemm_tn256_shape(N, Ktot);
+  const int tw = t256 ? 256 : 128;
+  const int n_tiles = (N + tw - 1) / tw;
+  *k_tiles = (Ktot + tw - 1) / tw;
   *out_tiles = n_tiles * *k_tiles;
   int sp;
   if (tn_big_shape(M, N, Ktot)) {
-    // transformer-sized dW (gemm_tn128_kernel, 2 workgroups per CU = 512 slots): pick the split count that minimises
+    // transformer-sized dW (gemm_tn128_kernel, 2 workgroups per CU = 512 slots; gemm_tn256_kernel: one 8-wave workgroup per CU = 256 slots
+    // whose 64-row step moves twice the bytes): pick the split count that minimises
     // (rounds of workgroups) x (64-row steps per split) + the cost of summing the partial tiles.  Plain "enough workgroups"
     // planning lands on e.g. 144 tiles x 8 splits = 2.25 rounds, i.e. a third of the machine idle in the last round.
-    const int slots = 512, total_steps = (M + 63) / 64;
+    const int slots = t256 ? 256 : 512, total_steps = (M + 63) / 64;
     double best = 1e30;
     sp = 1;
     for (int s = 1; s <= 512 && s * 4 <= total_steps + 3; ++s) {  // at least ~4 steps (256 rows) per split
       const int rounds = (*out_tiles * s + slots - 1) / slots;
       const int steps = (total_steps + s - 1) / s;
-      const double t = (double)rounds * steps * 1.8 + (double)(s + 1) * (double)N * Ktot * 4.0 / 3.0e6;  // microseconds
+      const double t = (double)rounds * steps * (t256 ? 2.2 : 1.8) + (double)(s + 1) * (double)N * Ktot * 4.0 / 3.0e6;  // microseconds
       if (t < best) { best = t; sp = s; }
     }
   } else {
@@ -256,7 +260,8 @@ extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
 // direct-to-LDS kernel of gemm_big.hip, whose operands never pass through registers)
 extern "C" int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot) {
   // the direct-to-LDS kernel folds it only through a padded column of ones: needs K % 128 != 0 (gemm_big.hip)
-  if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot)) return (Ktot % 128) != 0 ? 1 : 0;
+  if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot))
+    return (Ktot % (gemm_tn256_shape(N, Ktot) ? 256 : 128)) != 0 ? 1 : 0;
   return M > 0 ? 1 : 0;
 }
 
@@ -309,6 +314,13 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
   } else if (!accumulate || skinny_shape || p.bias_part != nullptr) {
     return -2;
   }
+  // tn_plan counted 256-wide tiles where the direct-to-LDS kernel would use them (a property of the shape); a launch of that shape which
+  // that kernel cannot take (fp32, operand transforms, im2col, two sources, no scratch) runs gemm_tn_kernel on 128-wide tiles: same
+  // splits, same scratch, the tile grid of ITS tiling
+  if (!(dtype == CVH_DT_BF16 && !fx && p.part != nullptr && gemm_tn_big_eligible(p))) {
+    p.k_tiles = (p.Ktot + 127) / 128;
+    out_tiles = ((N + 127) / 128) * p.k_tiles;
+  }
   // plain operands, or a plain dY with act(c0 * x + c1) on X (the projection dW of the fused InvertedResidual blocks)
   const bool fx_ok = !fx || (p.dy_xf.mode == 0 && p.x_xf.mode == 1 && p.bias_part == nullptr);
   const bool skinny = skinny_shape && fx_ok && dtype == CVH_DT_BF16 && KH * KW == 1 && p.stride == 1 && p.pad == 0 && C2 == 0;
@@ -345,7 +357,7 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 1>), grid, dim3(256), 0, st, p);
     else return -1;
   } else if (dtype == CVH_DT_BF16 && p.part != nullptr && gemm_tn_big_eligible(p)) {  // transformer-sized linears (ViT-B / CLIP)
-    if (p.bias_part != nullptr && (p.Ktot % 128) == 0) return -2;  // cvh_gemm_dw_folds_bias() says so
+    if (p.bias_part != nullptr && (p.Ktot % (gemm_tn256_shape(p.N, p.Ktot) ? 256 : 128)) == 0) return -2;  // cvh_gemm_dw_folds_bias() says so
     const int rc = launch_gemm_tn_big(p, splits, st);
     if (rc) return rc;
   } else if (dtype == CVH_DT_BF16) {

@@ -504,6 +504,135 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gemm_tn256_kernel: the same direct-to-LDS dW product on a 256 x 256 output tile (round 5).
+// Why: cut into 128 x 128 tiles every workgroup re-streams its 128 dY columns and 128 X columns of every row, so the bytes moved from L2
+// into LDS are (N tiles x K tiles x 256) / (N + K) times the unique ones — 9.6x for ViT-B's 3072 x 768; a 256 x 256 tile halves that
+// factor (and the number of LDS fragment reads per MFMA).  Used for the ViT-B / CLIP sized products (N, K >= 512: gemm_tn256_shape).  8 waves as 4 (N) x 2 (K), each 64 x 128
+// = 2 x 4 accumulator tiles (128 registers); a 64-row step is 32 KB of dY + 32 KB of X, two steps in LDS (128 KB): one workgroup per CU.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Frag<bf16_t> frag_tr256(const unsigned char* img, int kk, int col0, int lane) {
+  const int i = lane & 15;
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  const int r = 8 * (lane >> 5) + (i >> 2);
+  const unsigned char* p = img + (kk * 8 + (col >> 5)) * 1024 + r * 64 + (col & 31) * 2;
+  const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
+  const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + 4 * 64));
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  return f;
+}
+
+constexpr int TN256_IMG = 64 * 256 * 2;      // one operand image of a 64-row step: 32 KB
+constexpr int TN256_BUF = 2 * TN256_IMG;     // dY image | X image
+
+template <bool RAGGED>
+__global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // 2 x (dY image 32 KB | X image 32 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 1, wave_k = wave & 1;
+  const int bid_ = xcd_chunk_id((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int bx = bid_ % (int)gridDim.x, by = bid_ / (int)gridDim.x;
+  const int n0 = (bx / p.k_tiles) * 256, k0 = (bx % p.k_tiles) * 256;
+  const int m_begin = by * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(p.dy);
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(p.src1);
+  const int N = p.N, K = p.Ktot;
+
+  // direct-to-LDS assignment: wave w fills the 16-row group kk = w & 3 of every step, column half w >> 2 (128 columns = four 1 KB blocks
+  // of 16 rows x 32 columns per operand); a lane carries 16 bytes: row lane >> 2 of the group, 8-column chunk lane & 3 of the block
+  const int ld_kk = wave & 3, ld_half = wave >> 2;
+  const int row_off = 16 * ld_kk + (lane >> 2);
+  const int col_off = 128 * ld_half + (lane & 3) * 8;
+  const bf16_t* gy = dy + (size_t)(m_begin + row_off) * N + n0 + col_off;
+  const bf16_t* gx = x + (size_t)(m_begin + row_off) * K + k0 + col_off;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_line);
+  const bool fold_bias = RAGGED && p.bias_part != nullptr;  // column K of the padded last k tile = a column of ones (see gemm_tn128_kernel)
+  const bf16_t* ones = reinterpret_cast<const bf16_t*>(g_ones_line);
+  auto issue = [&](int step, int buf) {
+    const bool ok = m_begin + step * 64 + row_off < m_end;
+    unsigned char* y_dst = smem + buf * TN256_BUF + (ld_kk * 8 + 4 * ld_half) * 1024;
+    unsigned char* x_dst = y_dst + TN256_IMG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kcol = k0 + col_off + j * 32;
+      const bool oky = ok && (!RAGGED || n0 + col_off + j * 32 < N);
+      const bool okx = ok && (!RAGGED || kcol < K);
+      glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
+      glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : ((fold_bias && ok && kcol == K) ? ones : zero), x_dst + j * 1024);
+    }
+  };
+
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero();
+
+  const int steps = (m_end - m_begin + 63) / 64;
+  if (steps > 0) {
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < steps) issue(st + 1, buf ^ 1);
+    const unsigned char* Yt = smem + buf * TN256_BUF;
+    const unsigned char* Xt = Yt + TN256_IMG;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const Frag<bf16_t> a0 = frag_tr256(Yt, kk, wave_n * 64, lane);
+      const Frag<bf16_t> a1 = frag_tr256(Yt, kk, wave_n * 64 + 32, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Frag<bf16_t> b = frag_tr256(Xt, kk, wave_k * 128 + 32 * j, lane);
+        mma32(acc[0][j], a0, b);
+        mma32(acc[1][j], a1, b);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  float* dst0 = p.part + (size_t)by * N * K;
+#pragma unroll
+  for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+    for (int fk = 0; fk < 4; ++fk) {
+      const int k = k0 + wave_k * 128 + fk * 32 + (lane & 31);
+      if (RAGGED && k >= K) {
+        if (fold_bias && k == K) {  // the ones column: bias_part[split][n]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
+            if (n < N) p.bias_part[(size_t)by * N + n] = acc[fn][fk][r];
+          }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wave_n * 64 + fn * 32 + acc_row(r, lane);
+        if (!RAGGED || n < N) dst0[(size_t)n * K + k] = acc[fn][fk][r];
+      }
+    }
+}
+
+// shapes the 256 x 256 tile takes: it must move fewer operand columns per row than the 128 x 128 tiling (a property of (N, K) alone, so
+// that the scratch planner, cvh_gemm_dw_folds_bias and the launch agree), CVH_TUNE key 19 = 1 switches it off (A/B runs)
+bool gemm_tn256_shape(int N, int Ktot) {
+  if (cvh_tune_get(CVH_TUNE_NO_TN256)) return false;
+  // measured (round 5, same box): ViT-B / CLIP sized products (768 ... 3072 wide) +3.7 % / +2.9 % on the whole step; the MobileViT sized ones
+  // (144 ... 720 x 144 ... 240) no faster at 1024 images and slower at 128 (one workgroup per CU hides less latency than two): those stay
+  // on the 128 x 128 tiles
+  if (N < 512 || Ktot < 512) return false;
+  const long long c128 = (long long)((N + 127) / 128) * ((Ktot + 127) / 128) * 256;
+  const long long c256 = (long long)((N + 255) / 256) * ((Ktot + 255) / 256) * 512;
+  return c256 < c128;
+}
+
 bool gemm_tn_big_eligible(const GemmTNParams& p) {
   if (cvh_tune_get(CVH_TUNE_BIG_GEMM) == 0) return false;
   const bool linear = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.src2 == nullptr;
@@ -512,6 +641,17 @@ bool gemm_tn_big_eligible(const GemmTNParams& p) {
 }
 
 int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st) {
+  if (gemm_tn256_shape(p.N, p.Ktot)) {  // (p.k_tiles was planned for 256-wide tiles by tn_plan)
+    const int out_tiles = ((p.N + 255) / 256) * ((p.Ktot + 255) / 256);
+    const bool ragged = (p.N % 256) != 0 || (p.Ktot % 256) != 0;
+    static DynSmemAttr attr_r, attr_p;
+    const void* fn = ragged ? reinterpret_cast<const void*>(gemm_tn256_kernel<true>) : reinterpret_cast<const void*>(gemm_tn256_kernel<false>);
+    if (hipError_t e = (ragged ? attr_r : attr_p).ensure(fn, 2 * TN256_BUF); e != hipSuccess) return (int)e;
+    if (ragged) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(out_tiles, splits), dim3(512), 2 * TN256_BUF, st, p);
+    else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(out_tiles, splits), dim3(512), 2 * TN256_BUF, st, p);
+    CVH_CHECK_LAUNCH();
+    return 0;
+  }
   const int out_tiles = ((p.N + 127) / 128) * ((p.Ktot + 127) / 128);
   if ((p.N % 128) == 0 && (p.Ktot % 128) == 0) hipLaunchKernelGGL(gemm_tn128_kernel<false>, dim3(out_tiles, splits), dim3(256), 2 * BUF_BYTES, st, p);
   else hipLaunchKernelGGL(gemm_tn128_kernel<true>, dim3(out_tiles, splits), dim3(256), 2 * BUF_BYTES, st, p);

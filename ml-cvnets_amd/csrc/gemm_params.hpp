@@ -55,6 +55,7 @@ struct GemmTNParams {
 
 // gemm_big.hip
 bool gemm_tn_big_eligible(const GemmTNParams& p);
+bool gemm_tn256_shape(int N, int Ktot);  // the direct-to-LDS dW product runs on 256 x 256 tiles for this (N, K)
 int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st);
 bool gemm_big_eligible(const ConvGemmParams& p);
 int launch_gemm_big(const ConvGemmParams& p, hipStream_t st);

@@ -61,14 +61,25 @@ def test_library_exports_every_declared_symbol():
 
 def test_dw_split_planner_fills_whole_rounds():
     """host-side planning of the transformer-sized dW GEMM (csrc/gemm.hip tn_plan, no GPU needed): scratch = splits * N * K floats;
-    the split count must make (output tiles x splits) land just under a multiple of the 512 workgroup slots instead of just over."""
+    the split count must make (output tiles x splits) land just under a multiple of the workgroup slots instead of just over.  Round 5: the
+    direct-to-LDS kernel takes 256 x 256 tiles (one 8-wave workgroup per CU: 256 slots) wherever that moves fewer operand columns per row
+    than 128 x 128 tiles (two workgroups per CU: 512 slots) and both dimensions are >= 512 (ViT-B / CLIP) — csrc/gemm_big.hip gemm_tn256_shape."""
     from cvnets_amd import _lib
+
+    def tiling(N, K):
+        c128 = -(-N // 128) * -(-K // 128) * 256
+        c256 = -(-N // 256) * -(-K // 256) * 512
+        return (-(-N // 256) * -(-K // 256), 256) if (c256 < c128 and min(N, K) >= 512) else (-(-N // 128) * -(-K // 128), 512)
+
     M = 128 * 197  # ViT-B tokens at batch 128
-    for N, K, tiles in ((3072, 768, 144), (768, 768, 36), (2304, 768, 108), (768, 3072, 144)):
-        splits = _lib.query("cvh_gemm_dw_scratch_elems", M, N, K) // (N * K)
-        rounds = tiles * splits / 512.0
-        assert 1 <= splits <= 32 and (N * K * splits) == _lib.query("cvh_gemm_dw_scratch_elems", M, N, K)
-        assert rounds <= 1.0 or (rounds % 1.0) >= 0.85 or (rounds % 1.0) == 0.0, (N, K, splits, rounds)
+    for N, K in ((3072, 768), (768, 768), (2304, 768), (768, 3072), (144, 144), (432, 144), (576, 192), (720, 240), (96, 96)):
+        tiles, slots = tiling(N, K)
+        for rows in (M, 1 << 20):
+            splits = _lib.query("cvh_gemm_dw_scratch_elems", rows, N, K) // (N * K)
+            rounds = tiles * splits / float(slots)
+            assert 1 <= splits <= 512 and (N * K * splits) == _lib.query("cvh_gemm_dw_scratch_elems", rows, N, K)
+            assert rounds <= 1.0 or (rounds % 1.0) >= 0.85 or (rounds % 1.0) == 0.0, (N, K, rows, splits, rounds)
+    assert tiling(144, 144) == (4, 512) and tiling(720, 240) == (12, 512) and tiling(512, 512) == (4, 256) and tiling(3072, 768) == (36, 256)
     # small conv-style problems keep the many-split plan (tall-skinny dW: one 128x128 tile, reduction over 2M pixels)
     assert _lib.query("cvh_gemm_dw_scratch_elems", 128 * 128 * 128, 128, 32) // (128 * 32) >= 256
 

@@ -261,7 +261,7 @@ extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
 extern "C" int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot) {
   // the direct-to-LDS kernel folds it only through a padded column of ones: needs K % 128 != 0 (gemm_big.hip)
   if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot))
-    return (Ktot % (gemm_tn256_shape(N, Ktot) ? 256 : 128)) != 0 ? 1 : 0;
+    return gemm_tn256_shape(N, Ktot) ? 1 : ((Ktot % 128) != 0 ? 1 : 0);  // the 256 x 256 kernel sums the columns itself where K leaves no padded column
   return M > 0 ? 1 : 0;
 }
 
@@ -357,7 +357,7 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 1>), grid, dim3(256), 0, st, p);
     else return -1;
   } else if (dtype == CVH_DT_BF16 && p.part != nullptr && gemm_tn_big_eligible(p)) {  // transformer-sized linears (ViT-B / CLIP)
-    if (p.bias_part != nullptr && (p.Ktot % (gemm_tn256_shape(p.N, p.Ktot) ? 256 : 128)) == 0) return -2;  // cvh_gemm_dw_folds_bias() says so
+    if (p.bias_part != nullptr && !gemm_tn256_shape(p.N, p.Ktot) && (p.Ktot % 128) == 0) return -2;  // cvh_gemm_dw_folds_bias() says so
     const int rc = launch_gemm_tn_big(p, splits, st);
     if (rc) return rc;
   } else if (dtype == CVH_DT_BF16) {

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
   const bf16_t* gy = dy + (size_t)(m_begin + row_off) * N + n0 + col_off;
   const bf16_t* gx = x + (size_t)(m_begin + row_off) * K + k0 + col_off;
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_line);
-  const bool fold_bias = RAGGED && p.bias_part != nullptr;  // column K of the padded last k tile = a column of ones (see gemm_tn128_kernel)
+  const bool fold_bias = RAGGED && p.bias_part != nullptr && (K % 256) != 0;  // column K of the padded last k tile = a column of ones (see gemm_tn128_kernel)
   const bf16_t* ones = reinterpret_cast<const bf16_t*>(g_ones_line);
   auto issue = [&](int step, int buf) {
     const bool ok = m_begin + step * 64 + row_off < m_end;
@@ -569,6 +569,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero();
+  // Bias gradient when K is a multiple of 256 (no padded column to carry ones: every ViT-B / CLIP linear): the k-tile-0 workgroup of each
+  // (n tile, split) sums the columns of the dY image it has in LDS anyway — thread (row group tid >> 5, 8-column chunk tid & 31) reads
+  // 16 bytes of 4 rows per step; 32 adds per step next to 32 MFMAs.  Replaces a separate pass over dY per layer (cvh_colsum).
+  const bool colsum = p.bias_part != nullptr && !fold_bias && k0 == 0;
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  const int cs_off = ((tid & 31) >> 2) * 1024 + (tid >> 5) * 64 + (tid & 3) * 16;  // block of the column chunk + row in its 16-row group + chunk in the block
 
   const int steps = (m_end - m_begin + 63) / 64;
   if (steps > 0) {
@@ -581,6 +589,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
     if (st + 1 < steps) issue(st + 1, buf ^ 1);
     const unsigned char* Yt = smem + buf * TN256_BUF;
     const unsigned char* Xt = Yt + TN256_IMG;
+    if (colsum) {  // rows past the end of the split were fetched from the zero line
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        V8<bf16_t> v;
+        v.d = *reinterpret_cast<const uint4*>(Yt + q * 8 * 1024 + cs_off);
+        float f[8];
+        v8_unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += f[j];
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const Frag<bf16_t> a0 = frag_tr256(Yt, kk, wave_n * 64, lane);
@@ -594,6 +613,25 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+
+  if (colsum) {
+    // 16 row groups hold partial sums of the same 8 columns: lanes l and l + 32 of a wave first (row groups 2w, 2w + 1), then the 8 waves
+    // through LDS (free after the loop's last barrier) in wave order — a fixed tree, like every other reduction of the step
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] += __shfl_xor(cs[j], 32, 64);
+    float* red = reinterpret_cast<float*>(smem);  // [8 waves][256 columns]
+    if (lane < 32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave * 256 + (lane & 31) * 8 + j] = cs[j];
+    }
+    __syncthreads();
+    if (tid < 256 && n0 + tid < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[w * 256 + tid];
+      p.bias_part[(size_t)by * N + n0 + tid] = t;
+    }
   }
 
   float* dst0 = p.part + (size_t)by * N * K;

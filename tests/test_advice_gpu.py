@@ -81,10 +81,14 @@ def test_failed_backward_does_not_poison_the_next_one():
         cvnets_amd.set_compute_dtype(None)
 
 
-@pytest.mark.parametrize("M,N,K", [(70000, 288, 144), (40001, 144, 288), (33000, 432, 144), (20000, 192, 192), (9000, 96, 64)])
+@pytest.mark.parametrize("M,N,K", [(70000, 288, 144), (40001, 144, 288), (33000, 432, 144), (20000, 192, 192), (9000, 96, 64),
+                                   # gemm_tn256_kernel (N, K >= 512): K a multiple of 256 -> column sums inside the kernel; N ragged; K ragged -> ones column
+                                   (30000, 768, 768), (21011, 1536, 512), (9000, 520, 768), (12000, 768, 520), (5000, 3072, 768)])
 def test_dw_kernel_emits_bias_gradient_through_ones_column(M, N, K):
-    """gemm_tn128_kernel: the first zero-padded column of the last k tile is fed with ones, so output column K = column sums of dY = the bias
-    gradient of the same layer (LinearLayer backward, cvnets/layers/linear_layer.py:74-91) — checked against a plain sum and the dW itself."""
+    """gemm_tn128_kernel / gemm_tn256_kernel: the first zero-padded column of the last k tile is fed with ones, so output column K = column
+    sums of dY = the bias gradient of the same layer (LinearLayer backward, cvnets/layers/linear_layer.py:74-91); where K leaves no padded
+    column (multiples of 256 on the 256 x 256 tiles) the k-tile-0 workgroups sum the columns of the dY image they hold — checked against a
+    plain sum and the dW itself."""
     from cvnets_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(M)
     dy = torch.randn(M, N, device="cuda", generator=g).bfloat16()

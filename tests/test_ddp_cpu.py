@@ -409,3 +409,60 @@ def test_boundary_overlap_learns_the_execution_order():
         assert all(ddp._bucket_of[net.cls_token] not in lst for lst in ddp._boundary_buckets.values())
     finally:
         dist.destroy_process_group()
+
+
+def _fallback_worker(rank, world, port, fail_rank, q):
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cvnets_amd import comm
+    dist.init_process_group("gloo", init_method="env://")
+
+    class _Fake:  # stands in for a communicator that came up (no GPU here): what matters is the agreement protocol around it
+        destroyed = False
+
+        def self_test(self):
+            pass
+
+        def destroy(self):
+            _Fake.destroyed = True
+
+    def fake_from_store(store, world_, rank_, dev, key):
+        uid = comm.Communicator.exchange_unique_id(store, rank_, key)   # the real rendezvous
+        assert len(uid) == 128
+        if rank_ == fail_rank:
+            raise RuntimeError("simulated: ncclCommInitRank failed on this rank")
+        return _Fake()
+
+    comm.Communicator.from_store = staticmethod(fake_from_store)
+    comm.available = lambda: True
+    torch.cuda.is_available = lambda: True
+    got = comm.init_default(torch.device("cuda", 0))
+    q.put((rank, got is None, _Fake.destroyed, comm.default() is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [1, -1])
+def test_own_communicator_fallback_is_a_collective_decision(fail_rank):
+    """comm.init_default on two ranks: if ONE rank cannot bring its communicator up, every rank must fall back to torch.distributed (a
+    communicator that exists on some ranks only would leave the ranks on different data planes) and the rank that did come up destroys its
+    communicator; when all succeed, all keep it.  The RCCL calls are stubbed (no GPU here); the rendezvous and the MIN all-reduce of the
+    success flag on the control plane are the real ones."""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    from cvnets_amd import comm
+    if not comm.available():
+        pytest.skip("librccl not installed on this box")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fallback_worker, args=(r, 2, port, fail_rank, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=180) for _ in range(2))}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    if fail_rank >= 0:
+        assert got[0] == [True, True, True] and got[1][0] and got[1][2], got    # both None; rank 0's communicator was destroyed
+    else:
+        assert got[0] == [False, False, False] and got[1] == [False, False, False], got

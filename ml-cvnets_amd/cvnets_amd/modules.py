@@ -156,27 +156,32 @@ class TransformerEncoder(nn.Module):
 
     def forward_tokens(self, x: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None) -> Tensor:
         ln1, mha, drop1 = self.pre_norm_mha[0], self.pre_norm_mha[1], self.pre_norm_mha[2]
-        ln2, fc1, act, drop_ffn, fc2, drop2 = (self.pre_norm_ffn[i] for i in range(6))
         if not isinstance(ln1, nn.LayerNorm):
             raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
         p1 = drop1.p if self.training else 0.0
-        p2 = drop2.p if self.training else 0.0
-        pf = drop_ffn.p if self.training else 0.0  # ffn_dropout (transformer.py:92; 0.0 in every shipped YAML): un-fused — a standalone pass over the hidden tensor
         sd = self.drop_path.p if (self.training and isinstance(self.drop_path, StochasticDepth)) else 0.0
         if sd > 0.0:
             # x = x + StochasticDepth(Dropout(branch(LN(x)))): one Bernoulli draw per sample scales the whole branch; the residual add rides in
             # the drop-path kernel instead of the GEMM epilogue (transformer.py:140-155)
             y = ops.layer_norm_tokens(x, ln1, seqmap)
             x = ops.drop_path(mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1), x, sd, True, seqmap)
-            y = ops.layer_norm_tokens(x, ln2, seqmap)
-            h = ops.dropout(ops.linear(y, fc1.weight, fc1.bias, act=act_code(act)), pf, pf > 0.0)
-            h = ops.linear(h, fc2.weight, fc2.bias, drop_p=p2)
-            return ops.drop_path(h, x, sd, True, seqmap)
+            return self._ffn_tokens(x, seqmap, sd)
         # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue; the fork x -> (x, LN(x)) is one autograd
         # node, so the two gradients of x meet inside the LayerNorm backward kernel
         x, y = ops.layer_norm_fork(x, ln1, seqmap)
         x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x)
-        # x = x + Dropout(W2 act(W1 LN(x)))
+        return self._ffn_tokens(x, seqmap, 0.0)
+
+    def _ffn_tokens(self, x: Tensor, seqmap, sd: float) -> Tensor:
+        """x + StochasticDepth(Dropout(W2 Dropout(act(W1 LN(x)))))   (transformer.py:153-154)"""
+        ln2, fc1, act, drop_ffn, fc2, drop2 = (self.pre_norm_ffn[i] for i in range(6))
+        p2 = drop2.p if self.training else 0.0
+        pf = drop_ffn.p if self.training else 0.0  # ffn_dropout (transformer.py:92; 0.0 in every shipped YAML): un-fused — a standalone pass over the hidden tensor
+        if sd > 0.0:
+            y = ops.layer_norm_tokens(x, ln2, seqmap)
+            h = ops.dropout(ops.linear(y, fc1.weight, fc1.bias, act=act_code(act)), pf, pf > 0.0)
+            h = ops.linear(h, fc2.weight, fc2.bias, drop_p=p2)
+            return ops.drop_path(h, x, sd, True, seqmap)
         x, y = ops.layer_norm_fork(x, ln2, seqmap)
         a = act_code(act)
         if pf > 0.0:
@@ -190,10 +195,31 @@ class TransformerEncoder(nn.Module):
         # fc2's dX GEMM applies act'(pre) in its epilogue and returns the gradient of fc1's pre-activation directly
         return ops.linear(h, fc2.weight, fc2.bias, drop_p=p2, residual=x, in_pre=pre, in_act=a)
 
+    def _forward_cross(self, x: Tensor, x_prev: Tensor, key_padding_mask: Optional[Tensor], attn_mask: Optional[Tensor]) -> Tensor:
+        """transformer.py:131-155 with x_kv = x_prev: the query is LN(x), key and value come from x_prev AS GIVEN (the reference does not
+        normalise it).  Used by the spatio-temporal MobileViT block only, so it is composed from the hot path's ops (layers.py
+        `_cross_attention`) instead of riding the fused epilogues of the self-attention path."""
+        ln1, mha, drop1 = self.pre_norm_mha[0], self.pre_norm_mha[1], self.pre_norm_mha[2]
+        if not isinstance(ln1, nn.LayerNorm):
+            raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
+        b, s, c = x.shape
+        seqmap = (b, s, 1, 1, s, 1, s)
+        x2 = x.reshape(b * s, c)
+        if x2.dtype != ops.compute_dtype():
+            x2 = x2.to(ops.compute_dtype())
+        x2 = x2.contiguous()
+        p1 = drop1.p if self.training else 0.0
+        sd = self.drop_path.p if (self.training and isinstance(self.drop_path, StochasticDepth)) else 0.0
+        y = ops.layer_norm_tokens(x2, ln1, seqmap)
+        a = mha(y.view(b, s, c), x_kv=x_prev, key_padding_mask=key_padding_mask, attn_mask=attn_mask).reshape(b * s, c)
+        a = ops.dropout(a, p1, p1 > 0.0)
+        x2 = ops.drop_path(a, x2, sd, sd > 0.0, seqmap)
+        return self._ffn_tokens(x2, seqmap, sd).view(b, s, c)
+
     def forward(self, x: Tensor, x_prev: Optional[Tensor] = None, key_padding_mask: Optional[Tensor] = None,
                 attn_mask: Optional[Tensor] = None, *args, **kwargs) -> Tensor:
         if x_prev is not None:
-            raise NotImplementedError("cross-attention (x_prev) is not on the HIP hot path")
+            return self._forward_cross(x, x_prev, key_padding_mask, attn_mask)
         b, s, c = x.shape
         causal = False
         if attn_mask is not None:
@@ -285,9 +311,46 @@ class MobileViTBlock(nn.Module):
             fm = self.fusion(res, x2=fm)  # conv over cat(res, fm) without materialising the cat
         return fm
 
+    def forward_temporal(self, x: Tensor, x_prev: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """mobilevit_block.py:289-314: the block of the spatio-temporal MobileViT.  Every TransformerEncoder takes its keys / values from
+        `x_prev` — the patches [B*P, N, d] this method returned for the previous frame (None: plain self-attention) — and the patches after
+        the last global layer are returned beside the feature map.  Not a path of a §8 model: the patch sequences are materialised in the
+        reference's [B*P, N, d] order (torch permutations: plumbing) so that `x_prev` and the returned patches mean what they mean there,
+        and the layers run through their [B', S, C] entry points on the same kernels as the spatial path."""
+        x = ops.to_nhwc(x)
+        res = x
+        fm = self.local_rep.conv_1x1(self.local_rep.conv_3x3(x))
+        B, d, H, W = fm.shape
+        ph, pw = self.patch_h, self.patch_w
+        Hn, Wn = int(math.ceil(H / ph) * ph), int(math.ceil(W / pw) * pw)
+        interpolate = (Hn != H) or (Wn != W)
+        if interpolate:
+            fm = ops.resize_bilinear(fm, Hn, Wn)
+        n_h, n_w = Hn // ph, Wn // pw
+        # unfolding (mobilevit_block.py:185-232): [B, H, W, d] tokens -> [B, p_h, p_w, n_h, n_w, d] -> [B*P, N, d]
+        t = ops.tokens_of(fm).reshape(B, n_h, ph, n_w, pw, d)
+        patches = t.permute(0, 2, 4, 1, 3, 5).reshape(B * ph * pw, n_h * n_w, d)
+        for layer in self.global_rep:
+            if isinstance(layer, TransformerEncoder):
+                patches = layer(patches, x_prev=x_prev)
+            else:
+                if not isinstance(layer, nn.LayerNorm):
+                    raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
+                bp, n, _ = patches.shape
+                patches = ops.layer_norm_tokens(patches.reshape(bp * n, d).contiguous(), layer, (bp, n, 1, 1, n, 1, n)).view(bp, n, d)
+        # folding (mobilevit_block.py:234-266): back to the [B, H, W, d] token order
+        t = patches.view(B, ph, pw, n_h, n_w, d).permute(0, 3, 1, 4, 2, 5).reshape(B * Hn * Wn, d)
+        fm = ops.fmap_of(t, B, Hn, Wn)
+        if interpolate:
+            fm = ops.resize_bilinear(fm, H, W)
+        fm = self.conv_proj(fm)
+        if self.fusion is not None:
+            fm = self.fusion(res, x2=fm)
+        return fm, patches
+
     def forward(self, x: Union[Tensor, Tuple[Tensor]], *args, **kwargs) -> Union[Tensor, Tuple[Tensor, Tensor]]:
         if isinstance(x, Tuple) and len(x) == 2:
-            raise NotImplementedError("spatio-temporal MobileViT (forward_temporal) is not on the HIP hot path")
+            return self.forward_temporal(x=x[0], x_prev=x[1])
         if isinstance(x, Tensor):
             return self.forward_spatial(x)
         raise NotImplementedError

@@ -52,6 +52,21 @@ def reference_block(cin, d, ffn, blocks, head_dim, patch):
     return block
 
 
+def oracle_errors(sd, heads, blocks, patch, inputs, ref_out, ref_grads, names):
+    """(worst output, worst gradient) relative L2 distance of the oracle's two chained frames from the reference's"""
+    from oracle import mobilevit_oracle as orc
+
+    x1, x2, g, gp = (t.detach().clone() for t in inputs)
+    x1.requires_grad_(True), x2.requires_grad_(True)
+    leaf = {k: (v.detach().clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    fm1, p1 = orc.mobilevit_block_temporal(leaf, "", x1, None, blocks, heads, True, None, patch, patch)
+    fm2, p2 = orc.mobilevit_block_temporal(leaf, "", x2, p1, blocks, heads, True, None, patch, patch)
+    loss = (fm2 * g).sum() + (p2 * gp).sum()
+    grads = torch.autograd.grad(loss, [x1, x2] + [leaf[k] for k in names])
+    rel = lambda a, b: float((a.detach() - b.detach()).norm() / b.detach().norm())  # noqa: E731
+    return (max(rel(a, b) for a, b in zip((fm1, p1, fm2, p2), ref_out)), max(rel(a, b) for a, b in zip(grads, ref_grads)))
+
+
 def main():
     out = {}
     for name, b, cin, d, ffn, blocks, hd, patch, H, W in CASES:
@@ -68,6 +83,10 @@ def main():
         loss = (fm2 * g).sum() + (p2 * gp).sum()
         params = dict(block.named_parameters())
         grads = torch.autograd.grad(loss, [x1, x2] + list(params.values()))
+        # pin the oracle restatement (oracle/mobilevit_oracle.py: mobilevit_block_temporal) on what the reference just computed
+        errs = oracle_errors(sd, d // hd, blocks, patch, (x1, x2, g, gp), (fm1, p1, fm2, p2), grads, list(params.keys()))
+        print(f"{name}: oracle vs reference — outputs {errs[0]:.2e}, gradients {errs[1]:.2e}")
+        assert errs[0] < 1e-5 and errs[1] < 1e-4, errs
         out[f"{name}::cfg"] = np.array([b, cin, d, ffn, blocks, hd, patch, H, W])
         for k, v in (("fm1", fm1), ("p1", p1), ("fm2", fm2), ("p2", p2), ("grad_x1", grads[0]), ("grad_x2", grads[1])):
             out[f"{name}::{k}"] = v.detach().numpy()

@@ -143,14 +143,24 @@ def layer_norm(sd, prefix, x: Tensor, eps: float = 1e-5) -> Tensor:
 
 def multi_head_attention(sd, prefix, x: Tensor, num_heads: int,
                          attn_mask: Optional[Tensor] = None,
-                         key_padding_mask: Optional[Tensor] = None) -> Tensor:
-    """MultiHeadAttention.forward_default, self-attention branch
-    (cvnets/layers/multi_head_attention.py:135-239)."""
+                         key_padding_mask: Optional[Tensor] = None, x_kv: Optional[Tensor] = None) -> Tensor:
+    """MultiHeadAttention.forward_default (cvnets/layers/multi_head_attention.py:135-239): the self-attention branch (:148-157) and, with
+    `x_kv` [B, T, C], the cross-attention branch (:158-185: query from the first C rows of qkv_proj on x, key / value from the other 2C
+    rows on x_kv)."""
     b, s, c = x.shape
     hd = c // num_heads
-    qkv = F.linear(x, sd[prefix + ".qkv_proj.weight"], sd.get(prefix + ".qkv_proj.bias"))
-    qkv = qkv.reshape(b, s, 3, num_heads, hd).transpose(1, 3).contiguous()
-    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    w, bias = sd[prefix + ".qkv_proj.weight"], sd.get(prefix + ".qkv_proj.bias")
+    if x_kv is None:
+        qkv = F.linear(x, w, bias)
+        qkv = qkv.reshape(b, s, 3, num_heads, hd).transpose(1, 3).contiguous()
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    else:
+        t = x_kv.shape[1]
+        q = F.linear(x, w[:c], None if bias is None else bias[:c])
+        q = q.reshape(b, s, num_heads, hd).transpose(1, 2).contiguous()
+        kv = F.linear(x_kv, w[c:], None if bias is None else bias[c:])
+        kv = kv.reshape(b, t, 2, num_heads, hd).transpose(1, 3).contiguous()
+        k, v = kv[:, :, 0], kv[:, :, 1]
     q = q * (hd ** -0.5)
     attn = torch.matmul(q, k.transpose(-1, -2))
     if attn_mask is not None:
@@ -164,14 +174,16 @@ def multi_head_attention(sd, prefix, x: Tensor, num_heads: int,
 
 
 def transformer_encoder(sd, prefix, x: Tensor, num_heads: int, act: str = "swish",
-                        ln_eps: float = 1e-5, attn_mask=None, key_padding_mask=None, drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                        ln_eps: float = 1e-5, attn_mask=None, key_padding_mask=None, drop: Optional[Dict[str, Tensor]] = None,
+                        x_prev: Optional[Tensor] = None) -> Tensor:
     """TransformerEncoder.forward, drop_path Identity (cvnets/modules/transformer.py:129-156).  Dropout: p = 0 unless `drop` holds the
     multiplicative factors (0 or 1 / (1 - p), shaped like x) of the two `Dropout(p=dropout)` layers, transformer.py:82 (after the
     attention, key prefix + ".mha") and transformer.py:94 (after the second FFN linear, key prefix + ".ffn"); the generator that drew
     them is outside the oracle (the tests export the draws of the path under test).  ffn_dropout (transformer.py:92) stays 0."""
     res = x
     y = layer_norm(sd, prefix + ".pre_norm_mha.0", x, ln_eps)
-    y = multi_head_attention(sd, prefix + ".pre_norm_mha.1", y, num_heads, attn_mask, key_padding_mask)
+    # x_prev (transformer.py:131,143-150) is handed to the attention AS GIVEN: only the query side is normalised
+    y = multi_head_attention(sd, prefix + ".pre_norm_mha.1", y, num_heads, attn_mask, key_padding_mask, x_kv=x_prev)
     if drop is not None:
         y = y * drop[prefix + ".mha"]
     x = y + res
@@ -234,6 +246,25 @@ def mobilevit_block(sd, prefix, x: Tensor, n_blocks: int, num_heads: int, traini
     fm = conv_bn_act(sd, prefix + ".conv_proj", fm, training=training, bn_state=bn_state)
     fm = conv_bn_act(sd, prefix + ".fusion", torch.cat((res, fm), dim=1), training=training, bn_state=bn_state)
     return fm
+
+
+def mobilevit_block_temporal(sd, prefix, x: Tensor, x_prev: Optional[Tensor], n_blocks: int, num_heads: int, training: bool,
+                            bn_state, ph: int = 2, pw: int = 2) -> Tuple[Tensor, Tensor]:
+    """MobileViTBlock.forward_temporal  (cvnets/modules/mobilevit_block.py:289-314): forward_spatial with every TransformerEncoder reading
+    its keys / values from `x_prev` (the patches [B*P, N, d] returned for the previous frame; None = self-attention), returning the
+    patches after the last global layer beside the feature map.  Pinned on the reference by oracle/make_temporal_fixture.py."""
+    res = x
+    pre = prefix + "." if prefix else ""  # "" = the state dict of a bare block
+    fm = conv_bn_act(sd, pre + "local_rep.conv_3x3", x, training=training, bn_state=bn_state)
+    fm = conv_bn_act(sd, pre + "local_rep.conv_1x1", fm, use_norm=False, use_act=False)
+    patches, info = unfolding(fm, ph, pw)
+    for i in range(n_blocks):
+        patches = transformer_encoder(sd, f"{pre}global_rep.{i}", patches, num_heads, x_prev=x_prev)
+    patches = layer_norm(sd, f"{pre}global_rep.{n_blocks}", patches)
+    fm = folding(patches, info, ph, pw)
+    fm = conv_bn_act(sd, pre + "conv_proj", fm, training=training, bn_state=bn_state)
+    fm = conv_bn_act(sd, pre + "fusion", torch.cat((res, fm), dim=1), training=training, bn_state=bn_state)
+    return fm, patches
 
 
 def mobilevit_forward(sd: Dict[str, Tensor], x: Tensor, mode: str = "small", num_heads: int = 4,

@@ -122,6 +122,31 @@ def test_oracle_mha_matches_reference_fixture():
         assert np.allclose(o.numpy(), gold[f"case{idx}_out"], rtol=1e-4, atol=1e-5), idx
 
 
+def test_oracle_temporal_block_matches_reference_fixture():
+    """MobileViTBlock.forward((x, x_prev)) (mobilevit_block.py:289-326): the oracle's two chained frames against the reference's own run
+    (oracle/make_temporal_fixture.py): both feature maps, both patch tensors, every gradient — the second frame cross-attends to the first
+    one's patches, so this also pins the oracle's cross-attention branch (multi_head_attention.py:158-185) and `x_prev` hand-over."""
+    gold = np.load(os.path.join(GOLD, "mobilevit_block_temporal.npz"))
+    for case in ("even", "resized"):
+        b, cin, d, ffn, blocks, hd, patch, H, W = (int(v) for v in gold[f"{case}::cfg"])
+        shapes = {str(k): tuple(int(i) for i in str(s).split(",") if i) for k, s in zip(gold[f"{case}::keys"], gold[f"{case}::shapes"])}
+        sd = seeded_state_dict(shapes, seed=21)
+        names = [k[len(case) + 8:] for k in gold.files if k.startswith(f"{case}::grad::")]
+        assert len(names) == 36
+        leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+        x1 = seeded_input((b, cin, H, W), seed=31).requires_grad_(True)
+        x2 = seeded_input((b, cin, H, W), seed=32).requires_grad_(True)
+        fm1, p1 = orc.mobilevit_block_temporal(leaf, "", x1, None, blocks, d // hd, True, None, patch, patch)
+        fm2, p2 = orc.mobilevit_block_temporal(leaf, "", x2, p1, blocks, d // hd, True, None, patch, patch)
+        loss = (fm2 * seeded_input(tuple(fm2.shape), seed=33)).sum() + (p2 * seeded_input(tuple(p2.shape), seed=34)).sum()
+        grads = torch.autograd.grad(loss, [x1, x2] + [leaf[k] for k in names])
+        for key, got in (("fm1", fm1), ("p1", p1), ("fm2", fm2), ("p2", p2), ("grad_x1", grads[0]), ("grad_x2", grads[1])):
+            assert np.allclose(got.detach().numpy(), gold[f"{case}::{key}"], rtol=1e-4, atol=1e-5), (case, key)
+        for k, got in zip(names, grads[2:]):
+            want = gold[f"{case}::grad::{k}"]
+            assert float(np.linalg.norm(got.numpy() - want)) <= 1e-4 * float(np.linalg.norm(want)) + 1e-7, (case, k)
+
+
 def test_weights_are_platform_independent():
     t = seeded_state_dict({"conv_1.block.conv.weight": (16, 3, 3, 3)}, seed=0)["conv_1.block.conv.weight"]
     # fixed known-answer values (PCG64 stream): guards against numpy RNG drift between the authoring box and the GPU box

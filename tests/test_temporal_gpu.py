@@ -85,3 +85,49 @@ def test_temporal_first_frame_is_the_spatial_block():
         cvnets_amd.set_compute_dtype(None)
     assert tuple(patches.shape) == (3 * 4, 8 * 10, 64)
     assert _rel(fm.float(), a) < 1e-5
+
+
+@pytest.mark.parametrize("T,dtype", [(20, torch.float32), (50, torch.float32), (36, torch.bfloat16)])
+def test_temporal_block_against_the_oracle_with_a_foreign_x_prev(T, dtype):
+    """x_prev need not have the current frame's patch count (another resolution of the previous frame): T != N goes through the padded
+    cross-attention; checked against the CPU oracle (pinned on the reference by oracle/make_temporal_fixture.py), outputs and the gradients
+    of x, x_prev and every parameter.  bf16: rounding only (bounds = what fp32-accumulating bf16 storage gives on a block this size)."""
+    import cvnets_amd
+    from cvnets_amd.layers import default_opts
+    from cvnets_amd.modules import MobileViTBlock
+    from oracle import mobilevit_oracle as orc
+    from oracle.weights import seeded_input, seeded_state_dict
+
+    b, cin, d, ffn, blocks, hd, patch, H, W = 2, 32, 64, 128, 2, 16, 2, 12, 12
+    block = MobileViTBlock(default_opts(), in_channels=cin, transformer_dim=d, ffn_dim=ffn, n_transformer_blocks=blocks, head_dim=hd,
+                           patch_h=patch, patch_w=patch)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in block.state_dict().items()}, seed=22)
+    block.load_state_dict(sd)
+    block = block.to(DEV).train()
+    names = [k for k, _ in block.named_parameters()]
+    x = seeded_input((b, cin, H, W), seed=41)
+    xp = seeded_input((b * patch * patch, T, d), seed=42)
+    # oracle (CPU, fp32)
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    xo, xpo = x.clone().requires_grad_(True), xp.clone().requires_grad_(True)
+    fm_o, p_o = orc.mobilevit_block_temporal(leaf, "", xo, xpo, blocks, d // hd, True, None, patch, patch)
+    g, gp = seeded_input(tuple(fm_o.shape), seed=43), seeded_input(tuple(p_o.shape), seed=44)
+    want = torch.autograd.grad((fm_o * g).sum() + (p_o * gp).sum(), [xo, xpo] + [leaf[k] for k in names])
+    # HIP path
+    xg, xpg = x.to(DEV).requires_grad_(True), xp.to(DEV).requires_grad_(True)
+    cvnets_amd.set_compute_dtype(dtype)
+    try:
+        fm, p = block((xg, xpg))
+        loss = (fm.float() * g.to(DEV)).sum() + (p.float() * gp.to(DEV)).sum()
+        got = torch.autograd.grad(loss, [xg, xpg] + [dict(block.named_parameters())[k] for k in names])
+        torch.cuda.synchronize()
+    finally:
+        cvnets_amd.set_compute_dtype(None)
+    out_tol, grad_tol = (OUT_TOL, GRAD_TOL) if dtype == torch.float32 else (2e-2, 5e-2)
+    assert tuple(p.shape) == tuple(p_o.shape) == (b * patch * patch, (H // patch) * (W // patch), d)
+    assert _rel(fm.detach().float().cpu(), fm_o.detach()) < out_tol and _rel(p.detach().float().cpu(), p_o.detach()) < out_tol
+    num = sum(float((a.float().cpu().double() - w.double()).pow(2).sum()) for a, w in zip(got, want))
+    den = sum(float(w.double().pow(2).sum()) for w in want)
+    assert (num / den) ** 0.5 < grad_tol, (num / den) ** 0.5
+    for nm, a, w in zip(["x", "x_prev"], got[:2], want[:2]):
+        assert _rel(a.float().cpu(), w) < (grad_tol if dtype == torch.float32 else 1e-1), nm

@@ -155,3 +155,84 @@ def test_bf16_rounded_evaluation_is_chaotic_at_the_noise_level():
     l16p, _, _, _ = bf16_points.train_step(sd, xp, y, mode="xx_small")
     assert rel(l32p, l32) < 1e-4
     assert rel(l16p, l16) > 3e-3 and rel(l16p, l16) > 0.2 * rel(l16, l32)
+
+
+def test_temporal_block_host_composition_against_the_oracle(monkeypatch):
+    """MobileViTBlock.forward((x, x_prev)) (cvnets/modules/mobilevit_block.py:289-326) is HOST composition over the hot path's ops: patch
+    order, which tensors feed query / key / value, the padded cross-attention, where the residuals and the final LayerNorm sit.  With torch
+    stand-ins for the kernels (test doubles, CPU) the composition must reproduce the oracle — outputs and the gradients of x and x_prev — for
+    a first frame (x_prev = None), equal patch counts, and foreign patch counts on either side (T < N and T > N)."""
+    import torch.nn.functional as F
+
+    from cvnets_amd import ops
+    from cvnets_amd.layers import default_opts
+    from cvnets_amd.modules import MobileViTBlock
+    from oracle import mobilevit_oracle as orc
+    from oracle.weights import seeded_input, seeded_state_dict
+
+    def linear(x, w, b=None, *, act=ops.ACT_NONE, drop_p=0.0, residual=None, expose_pre=False, in_pre=None, in_act=ops.ACT_NONE):
+        pre = F.linear(x, w, b)
+        y = F.silu(pre) if act == ops.ACT_SILU else pre
+        assert act in (ops.ACT_NONE, ops.ACT_SILU) and drop_p == 0.0
+        if residual is not None:
+            y = y + residual
+        return (y, pre) if expose_pre else y  # (in_pre / in_act only steer the fused backward: the input is already the activated tensor)
+
+    def attention(qkv, heads, seqmap, causal=False, key_padding_mask=None, drop_p=0.0):
+        b, L = seqmap[0], seqmap[1]
+        assert tuple(seqmap[2:]) == (1, 1, L, 1, L) and not causal and drop_p == 0.0
+        d = qkv.shape[1] // 3
+        q, k, v = qkv.view(b, L, 3, heads, d // heads).permute(2, 0, 3, 1, 4)
+        a = (q * (d // heads) ** -0.5) @ k.transpose(-1, -2)
+        if key_padding_mask is not None:
+            a = a.masked_fill(key_padding_mask.bool()[:, None, None, :], float("-inf"))
+        return (torch.softmax(a, -1) @ v).transpose(1, 2).reshape(b * L, d)
+
+    class TorchConv(torch.nn.Module):  # ConvLayer2d stand-in on NCHW tensors, same parameters
+        def __init__(self, layer):
+            super().__init__()
+            self.layer = layer
+
+        def forward(self, x, residual=None, x2=None):
+            blk = self.layer.block
+            if x2 is not None:
+                x = torch.cat((x, x2), dim=1)
+            k = blk.conv.weight.shape[-1]
+            y = F.conv2d(x, blk.conv.weight, blk.conv.bias, padding=(k - 1) // 2)
+            if "norm" in blk._modules:
+                y = F.batch_norm(y, None, None, blk.norm.weight, blk.norm.bias, training=True, eps=blk.norm.eps)
+            return F.silu(y) if "act" in blk._modules else y
+
+    monkeypatch.setattr(ops, "linear", linear)
+    monkeypatch.setattr(ops, "attention", attention)
+    monkeypatch.setattr(ops, "compute_dtype", lambda: torch.float32)
+    monkeypatch.setattr(ops, "to_nhwc", lambda x, dtype=None: x)
+    monkeypatch.setattr(ops, "layer_norm_tokens", lambda x, ln, seqmap: F.layer_norm(x, (x.shape[1],), ln.weight, ln.bias, ln.eps))
+    monkeypatch.setattr(ops, "layer_norm_fork", lambda x, ln, seqmap: (x, ops.layer_norm_tokens(x, ln, seqmap)))
+    monkeypatch.setattr(ops, "add", lambda a, b: a + b)
+    monkeypatch.setattr(ops, "resize_bilinear", lambda x, h, w: F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False))
+
+    b, cin, d, ffn, blocks, hd, patch = 2, 16, 32, 64, 2, 8, 2
+    block = MobileViTBlock(default_opts(), in_channels=cin, transformer_dim=d, ffn_dim=ffn, n_transformer_blocks=blocks, head_dim=hd,
+                           patch_h=patch, patch_w=patch).train()
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in block.state_dict().items()}, seed=23)
+    block.load_state_dict(sd)
+    block.local_rep.conv_3x3, block.local_rep.conv_1x1 = TorchConv(block.local_rep.conv_3x3), TorchConv(block.local_rep.conv_1x1)
+    block.conv_proj, block.fusion = TorchConv(block.conv_proj), TorchConv(block.fusion)
+    for (H, W), T in (((8, 8), None), ((8, 8), 16), ((8, 6), 5), ((7, 9), 40)):  # (7, 9): resized to 8 x 10 and back
+        x = seeded_input((b, cin, H, W), seed=51).requires_grad_(True)
+        xo = x.detach().clone().requires_grad_(True)
+        xp = xpo = None
+        if T is not None:
+            xp = seeded_input((b * patch * patch, T, d), seed=52).requires_grad_(True)
+            xpo = xp.detach().clone().requires_grad_(True)
+        fm, p = block((x, xp))
+        fm_o, p_o = orc.mobilevit_block_temporal(sd, "", xo, xpo, blocks, d // hd, True, None, patch, patch)
+        assert fm.shape == fm_o.shape and p.shape == p_o.shape
+        assert torch.allclose(fm, fm_o, rtol=1e-4, atol=1e-5) and torch.allclose(p, p_o, rtol=1e-4, atol=1e-5), (H, W, T)
+        g, gp = seeded_input(tuple(fm.shape), seed=53), seeded_input(tuple(p.shape), seed=54)
+        ins, ins_o = ([x], [xo]) if T is None else ([x, xp], [xo, xpo])
+        got = torch.autograd.grad((fm * g).sum() + (p * gp).sum(), ins)
+        want = torch.autograd.grad((fm_o * g).sum() + (p_o * gp).sum(), ins_o)
+        for a, w in zip(got, want):
+            assert torch.allclose(a, w, rtol=1e-3, atol=1e-5), (H, W, T)

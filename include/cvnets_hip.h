@@ -198,6 +198,10 @@ int cvh_dwconv_bn_bwd(int dtype, const void* g_out, const cvh_operand_xf* dy_xf,
  * w1 = [hid][Cin], wd = [9][hid] packed weights (cvh_weight_pack).  Replaces Conv2d(1x1) + BatchNorm2d + SiLU + Conv2d(groups = C) and
  * their autograd backward; returns -2 for geometries it does not cover (callers fall back to cvh_pw_gemm_bn + cvh_dwconv_bn_*). */
 int cvh_dwx_rows(int B, int Ho, int Wo, int hid, int stride);
+/* rows of cvh_dwx_fwd's stats_part.  Full strips (H % 8 == 0, W % 16 == 0, Cin <= 64, hid % 64 == 0) run the strip-streaming kernel of
+ * csrc/dwxs.hip: a loader wave per workgroup streams the block input top to bottom through LDS, expansion and stencil are one software
+ * pipeline, the rows two chunks share are computed once. */
+int cvh_dwx_fwd_rows(int B, int H, int W, int Cin, int hid, int stride);
 /* out[i] = alpha * a[i] + (b ? b[i] : 0): the column sums s = 1^T x of an InvertedResidual OUTPUT without reading it — the block ends in a
  * train-mode BatchNorm (cvnets/modules/mobilenetv2.py:208-219, batch_norm.py:14-49), so sum_rows bn(y)[c] = rows * beta[c] (+ the input's
  * column sums on the residual path); feeds cvh_gram_bn_stats of the next block. */

@@ -66,8 +66,15 @@ struct DwxFwdParams {
   int act1;
   int B, H, W, Ho, Wo, hid;
   int tiles_h, tiles_w, ntiles, chunks;
-  int dbg;  // developer knob (CVH_TUNE key 17): skip phases to time them (results are WRONG when non-zero)
+#ifdef CVH_DWX_DBG
+  int dbg;  // developer knob (CVH_TUNE key 17, -DCVH_DWX_DBG builds only): skip phases to time them (results are WRONG when non-zero)
+#endif
 };
+#ifdef CVH_DWX_DBG
+#define DX_DBG(p_, bit_) ((p_).dbg & (bit_))
+#else
+#define DX_DBG(p_, bit_) 0
+#endif
 
 // LDS pitch of the x tiles: dense rows for one 32-wide K step (2-way conflicts on the operand reads, 4 workgroups per CU), + 16 B otherwise
 template <int CIN> __host__ __device__ constexpr int dx_xp() { return 32 * ((CIN + 31) / 32) + (CIN <= 32 ? 0 : 8); }
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
       stage_x(xs0);
     }
     __syncthreads();  // buffer `cur` is complete; every wave has left the previous tile (whose x lived in the other buffer)
-    const bool has_next = tix + t_step < p.ntiles && !(p.dbg & 16);
+    const bool has_next = tix + t_step < p.ntiles && !DX_DBG(p, 16);
     if (has_next) load_x(tix + t_step);  // next tile's input, in flight under this tile's expansion phase
 
     // pixels of the halo tile that lie inside the image (the conv's zero padding applies to the ACTIVATED tensor); interior tiles —
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
     // pb - 1 stores to LDS (the compiler cannot hoist an LDS read above an LDS store it cannot disambiguate, and a wave that waits
     // for its reads, then for its MFMAs, then runs its epilogue, leaves the SIMD idle two thirds of the time at 2-4 waves per SIMD),
     // and the MFMAs of block pb run under the VALU work of block pb - 1.
-    if (!(p.dbg & 4)) {
+    if (!DX_DBG(p, 4)) {
       bf16x8_t bq[KS];
       auto rd = [&](int pb) __attribute__((always_inline)) {
         const bf16_t* xrow = xs + (16 * pb + l15) * XP + 8 * l4;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
     }
 
     // ---- depthwise stencil on the matrix pipe (two accumulators: the five products of a block are not one dependent chain) ----
-    if (!(p.dbg & 8)) {
+    if (!DX_DBG(p, 8)) {
       bf16x8_t fq[5];
       auto rd = [&](int ob) __attribute__((always_inline)) {
         const int orow = S == 1 ? ob : 2 * ob + (l15 >> 3), ocol = S == 1 ? l15 : (l15 & 7);
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
       // results leave as 8-byte stores from the accumulator layout: tile base (wave-uniform) + the lane's precomputed offset; statistics
       // from the fp32 accumulators; tiles that overhang the image or a partial channel block take the checked path
       bf16_t* ybase = p.y2 + (((size_t)b * p.Ho + ho0) * p.Wo + wo0) * hid;
-      const bool fast = wave_full && ho0 + TL::OH <= p.Ho && wo0 + TL::OW <= p.Wo && !(p.dbg & 2);
+      const bool fast = wave_full && ho0 + TL::OH <= p.Ho && wo0 + TL::OW <= p.Wo && !DX_DBG(p, 2);
       auto epi = [&](int ob, const f32x2_t& lo, const f32x2_t& hi2) __attribute__((always_inline)) {
         if (fast) {  // wave-uniform fast path: no per-lane bounds arithmetic
           *reinterpret_cast<uint2*>(ybase + yoff0 + ob * ystep) = make_uint2(f2bf_pk(lo[0], lo[1]), f2bf_pk(hi2[0], hi2[1]));
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256, dx_fwd_occ<CIN>()) void dwx_fwd_kernel(DwxFwdP
           s2[1] += hi2 * hi2;
         } else {
           const int orow = S == 1 ? ob : 2 * ob + (l15 >> 3), ocol = S == 1 ? l15 : (l15 & 7);
-          if (ho0 + orow < p.Ho && wo0 + ocol < p.Wo && cw + 4 * l4 < hid && !(p.dbg & 2)) {
+          if (ho0 + orow < p.Ho && wo0 + ocol < p.Wo && cw + 4 * l4 < hid && !DX_DBG(p, 2)) {
             *reinterpret_cast<uint2*>(ybase + yoff0 + ob * ystep) = make_uint2(f2bf_pk(lo[0], lo[1]), f2bf_pk(hi2[0], hi2[1]));
             s1[0] += lo;
             s1[1] += hi2;
@@ -426,7 +433,6 @@ struct DwxBwdParams {
   int act1;
   int B, H, W, Ho, Wo, hid;
   int tiles_h, tiles_w, ntiles, chunks;
-  int dbg;      // developer knob (CVH_TUNE key 17)
 };
 
 template <int S, int CIN>
@@ -831,7 +837,21 @@ int dwx_plan(int B, int Ho, int Wo, int hid, int stride, int* tiles_h, int* tile
 
 }  // namespace
 
-/* rows of the partial-statistics / partial-dW buffers of cvh_dwx_fwd / cvh_dwx_bwd (= workgroups per 64-channel chunk) */
+// strip-streaming forward kernel (csrc/dwxs.hip)
+bool dwxs_fwd_plan(int B, int H, int W, int Cin, int hid, int stride, int* rows, int* nstrip, int* nseg, int* RS);
+int dwxs_fwd_launch(const void* x, const void* w1, const float* scale1, const float* shift1, const void* wd, void* y2, float* stats_part, int B, int H,
+                    int W, int Ho, int Wo, int Cin, int hid, int stride, hipStream_t st);
+
+/* rows of the partial-statistics buffer of cvh_dwx_fwd */
+extern "C" int cvh_dwx_fwd_rows(int B, int H, int W, int Cin, int hid, int stride) {
+  if (B <= 0 || hid <= 0 || (hid % 8) || (stride != 1 && stride != 2)) return -2;
+  int rows, ns, ng, rs;
+  if (dwxs_fwd_plan(B, H, W, Cin, hid, stride, &rows, &ns, &ng, &rs)) return rows;
+  int th, tw, ch;
+  return dwx_plan(B, (H + 2 - 3) / stride + 1, (W + 2 - 3) / stride + 1, hid, stride, &th, &tw, &ch);
+}
+
+/* rows of the partial-statistics / partial-dW buffers of cvh_dwx_bwd (= workgroups per 64-channel chunk) */
 extern "C" int cvh_dwx_rows(int B, int Ho, int Wo, int hid, int stride) {
   if (B <= 0 || hid <= 0 || (hid % 8) || (stride != 1 && stride != 2)) return -2;
   int th, tw, ch;
@@ -860,13 +880,22 @@ extern "C" int cvh_dwx_fwd(int dtype, const void* x, const void* w1, const float
   if (!dwx_cin_ok(Cin) || (stride == 1 && Cin > 64) || hid <= 0 || (hid % 8) || (stride != 1 && stride != 2)) return -2;
   if (Ho != (H + 2 - 3) / stride + 1 || Wo != (W + 2 - 3) / stride + 1) return -2;
   if (B <= 0) return 0;
+  {
+    int rows, ns, ng, rs;
+    if (dwxs_fwd_plan(B, H, W, Cin, hid, stride, &rows, &ns, &ng, &rs)) {
+      cvh_family_tally(0, ((long long)B * H * W * Cin + (long long)B * Ho * Wo * hid) * 2);
+      return dwxs_fwd_launch(x, w1, scale1, shift1, wd, y2, stats_part, B, H, W, Ho, Wo, Cin, hid, stride, (hipStream_t)stream);
+    }
+  }
   DwxFwdParams p;
   p.x = reinterpret_cast<const bf16_t*>(x); p.w1 = reinterpret_cast<const bf16_t*>(w1); p.scale1 = scale1; p.shift1 = shift1;
   p.wd = reinterpret_cast<const bf16_t*>(wd); p.y2 = reinterpret_cast<bf16_t*>(y2); p.stats_part = stats_part; p.act1 = act1;
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.hid = hid;
   const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
   p.ntiles = B * p.tiles_h * p.tiles_w;
+#ifdef CVH_DWX_DBG
   p.dbg = cvh_tune_get(17);
+#endif
   cvh_family_tally(0, ((long long)B * H * W * Cin + (long long)B * Ho * Wo * hid) * 2);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);
@@ -912,7 +941,6 @@ extern "C" int cvh_dwx_bwd(int dtype, const void* x, const void* w1, const float
   p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.hid = hid;
   const int rows = dwx_plan(B, Ho, Wo, hid, stride, &p.tiles_h, &p.tiles_w, &p.chunks);
   p.ntiles = B * p.tiles_h * p.tiles_w;
-  p.dbg = cvh_tune_get(17);
   cvh_family_tally(1, ((long long)B * H * W * (Cin + hid) + (long long)B * Ho * Wo * hid * (y_out != nullptr ? 2 : 1)) * 2);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(rows * p.chunks);

@@ -36,6 +36,7 @@ SIGNATURES = {
     "cvh_stem_rows": [I, I, I, I],
     "cvh_ir_exp_bwd_rows": [L, I, I],
     "cvh_dwx_rows": [I, I, I, I, I],
+    "cvh_dwx_fwd_rows": [I, I, I, I, I, I],
     "cvh_axpb": [P, F, P, P, I, P],
     "cvh_gram_bn_stats": [P, P, P, P, I, I, I, P],
     "cvh_dwx_fwd": [I, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P],

@@ -198,7 +198,7 @@ class InvertedResidualFn(torch.autograd.Function):
                 st1 = ops._bn_forward(x, M1, hid, part, 1, g1, b1, rm1, rv1, True, mom[0], eps[0])
             part, R = None, 0
             if training:
-                R = _lib.query("cvh_dwx_rows", B, Ho, Wo, hid, stride)
+                R = _lib.query("cvh_dwx_fwd_rows", B, H, W, Cin, hid, stride)
                 part = _f32(R * 2 * hid, dev)
             _lib.call("cvh_dwx_fwd", _dt(x), _p(x), _p(wp1), _p(st1[2]), _p(st1[3]), act1, _p(wpd), _p(y2), _p(part), B, H, W, Ho, Wo, Cin, hid,
                       stride, _stream())

@@ -21,6 +21,15 @@ CASES = [  # (B, H, W, Cin, hid, stride)
     (2, 16, 16, 96, 384, 2),
     (2, 16, 16, 128, 512, 2),
     (1, 10, 12, 16, 72, 2),   # hid not a multiple of the 64-channel chunk
+    # full strips (H % 8 == 0, W % 16 == 0, hid % 64 == 0, Cin <= 64): the strip-streaming forward kernel (csrc/dwxs.hip)
+    (2, 24, 48, 16, 64, 1),    # three chunks per strip, left / interior / right strips
+    (1, 64, 32, 64, 256, 1),   # eight chunks, four channel chunks
+    (3, 8, 16, 64, 128, 1),    # single chunk: first and last rows in the same chunk
+    (2, 40, 32, 32, 128, 2),   # stride 2, five chunks
+    (1, 64, 64, 64, 256, 2),
+    (1000, 16, 16, 16, 64, 2), # more units than workgroups: several strips per workgroup
+    (300, 16, 32, 64, 64, 1),
+    (1, 128, 16, 32, 64, 1),   # one strip: the row segments are shortened to spread the workgroups
 ]
 
 
@@ -50,7 +59,7 @@ def test_dwx_fwd_matches_torch(B, H, W, Cin, hid, stride):
     _, x, w1, wd, scale, shift = _inputs(B, H, W, Cin, hid, 11 + H + hid)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     _, _, ref = _ref_forward(x, w1, wd, scale, shift, stride)
-    R = _lib.query("cvh_dwx_rows", B, Ho, Wo, hid, stride)
+    R = _lib.query("cvh_dwx_fwd_rows", B, H, W, Cin, hid, stride)
     y2 = torch.full((B, Ho, Wo, hid), float("nan"), device=DEV, dtype=torch.bfloat16)
     part = torch.full((R, 2, hid), float("nan"), device=DEV)
     _lib.call("cvh_dwx_fwd", 1, x.data_ptr(), w1.data_ptr(), scale.data_ptr(), shift.data_ptr(), 1, wd.data_ptr(), y2.data_ptr(), part.data_ptr(),

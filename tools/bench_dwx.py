@@ -34,10 +34,14 @@ def main():
     ap.add_argument("--only", default="both")
     ap.add_argument("--dbg", type=int, default=0, help="CVH_TUNE key 17: phase-skip bits of the dwx kernels (timing experiments; results wrong)")
     ap.add_argument("--shape", type=int, default=-1, help="index into SHAPES (-1: all)")
+    ap.add_argument("--tune", default="", help="CVH_TUNE settings key=value[,key=value] (20=1: tile kernel of dwx.hip instead of the strip kernel)")
     a = ap.parse_args()
     B = a.batch
     st = torch.cuda.current_stream().cuda_stream
     _lib.call("cvh_set_tuning", 17, a.dbg)
+    for kv in filter(None, a.tune.split(",")):
+        k, v = kv.split("=")
+        _lib.call("cvh_set_tuning", int(k), int(v))
     for (H, W, Cin, hid, s) in (SHAPES if a.shape < 0 else [SHAPES[a.shape]]):
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         g = torch.Generator(device=DEV).manual_seed(1)
@@ -53,7 +57,8 @@ def main():
         line = f"{H}x{W} Cin{Cin} hid{hid} s{s}: "
         if a.only in ("both", "new"):
             R = _lib.query("cvh_dwx_rows", B, Ho, Wo, hid, s)
-            part = torch.empty(R, 2, hid, device=DEV); dwp = torch.empty(R, hid * 9, device=DEV)
+            Rf = _lib.query("cvh_dwx_fwd_rows", B, H, W, Cin, hid, s)
+            part = torch.empty(max(R, Rf), 2, hid, device=DEV); dwp = torch.empty(R, hid * 9, device=DEV)
             tf = timed(lambda: _lib.call("cvh_dwx_fwd", 1, x.data_ptr(), w1.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), 1, wd.data_ptr(),
                                          y2.data_ptr(), part.data_ptr(), B, H, W, Ho, Wo, Cin, hid, s, st), a.reps)
             tb = timed(lambda: _lib.call("cvh_dwx_bwd", 1, x.data_ptr(), w1.data_ptr(), stats.data_ptr(), 1, g2.data_ptr(), y2.data_ptr(), ca.data_ptr(),

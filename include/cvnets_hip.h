@@ -421,6 +421,18 @@ int cvh_attn_bwd_drop(int dtype, const void* qkv, const void* out, const void* d
                       const unsigned char* kpm, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
                       int causal, float drop_p, const unsigned long long* seed, unsigned int stream_id, void* stream);
 
+/* The same with a general ADDITIVE attention mask (cvnets/layers/multi_head_attention.py:197-208: `attn = attn + attn_mask`, mask
+ * [N, S, T]; pinned by the reference's tests/modules/test_transformer.py): bias float32, natural units, -inf allowed, [S][S] shared by every
+ * sequence (bias_stride 0) or [nseq][S][S] (bias_stride >= S*S elements); added to the scaled scores before the softmax in the forward and
+ * in both recomputations of the backward.  bias == NULL is cvh_attn_fwd_drop / cvh_attn_bwd_drop; `causal` stays the generated fast path. */
+int cvh_attn_fwd_mask(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, const float* bias, long long bias_stride,
+                      int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling, int causal, float drop_p,
+                      const unsigned long long* seed, unsigned int stream_id, void* stream);
+int cvh_attn_bwd_mask(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                      const unsigned char* kpm, const float* bias, long long bias_stride, int nseq, int S, int h, int c, int ph, int pw,
+                      int n_w, int H, int W, float scaling, int causal, float drop_p, const unsigned long long* seed, unsigned int stream_id,
+                      void* stream);
+
 /* ---- data-parallel exchange on a communicator of its own (RCCL over xGMI) --------------------------------------------------------
  * Replaces what the reference reaches through torch.distributed: the rendezvous + communicator creation of utils/ddp_utils.py:47-89
  * (init_process_group("nccl") and the dummy all_reduce at :84-85), the gradient averaging of DistributedDataParallel (main_train.py:91-96),

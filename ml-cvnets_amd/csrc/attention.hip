@@ -33,6 +33,8 @@ struct AttnParams {
   float* lse;        // [nseq][h][S]
   float* dsum;       // [nseq][h][S]   D = rowsum(dO * O)
   const unsigned char* kpm;  // optional key padding mask [nseq][S] (nonzero = masked)
+  const float* bias;         // optional additive mask (multi_head_attention.py:197-208): [S][S] (bias_stride 0) or [nseq][S][S], natural-log units, -inf allowed
+  long long bias_stride;     // elements between the masks of consecutive sequences
   int nseq, S, h, c, d;
   SeqMap map;
   float scaling;
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_F) void attn_fwd_kerne
   }
 
   const int my_q = q0 + (lane & 31);
+  const float* bias_row = (FEAT && p.bias != nullptr && my_q < p.S) ? p.bias + (size_t)s * p.bias_stride + (size_t)my_q * p.S : nullptr;
   const bool drop = FEAT && p.drop_p > 0.f;
   const unsigned long long seed = drop ? *p.seed : 0ull;
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_F) void attn_fwd_kerne
     kvst.store(Ks, 1.0f, Vs, PQ, tid);           // rows past the sequence end arrive as zeros (V rows feed the MFMA k-dimension)
     if (kv0 + KB < p.S) load_kv(kv0 + KB);       // next tile's HBM reads fly under this tile's MFMA + softmax
     __syncthreads();
-    const bool full_tile = !causal && (!FEAT || p.kpm == nullptr) && kv0 + KB <= p.S;  // workgroup-uniform: no per-element visibility tests
+    const bool full_tile = !causal && (!FEAT || (p.kpm == nullptr && p.bias == nullptr)) && kv0 + KB <= p.S;  // workgroup-uniform: no per-element visibility tests
 
     // S^T[key][q] = sum_c K[key][c] * Qs[q][c]
     f32x16_t sacc[KB / 32];
@@ -435,7 +438,9 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_F) void attn_fwd_kerne
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool hide = dead[e] != 0 || (causal && key0 + e > my_q);
-            sacc[f][4 * i + e] = hide ? -INFINITY : sacc[f][4 * i + e];
+            float sv = sacc[f][4 * i + e];
+            if (FEAT && bias_row != nullptr && key0 + e < p.S) sv += bias_row[key0 + e] * kLog2e;  // scores are in log2 units
+            sacc[f][4 * i + e] = hide ? -INFINITY : sv;
           }
         }
     }
@@ -557,6 +562,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_Q) void attn_bwd_dq_ke
   const T* kcol = qkv + p.d + head * p.c;
   auto load_kv = [&](int kv0) { kvst.load(kcol, ld, kcol + p.d, ld, rk + kv0, p.c, tid); };
   const int my_q = q0 + (lane & 31);
+  const float* bias_row = (FEAT && p.bias != nullptr && my_q < p.S) ? p.bias + (size_t)s * p.bias_stride + (size_t)my_q * p.S : nullptr;
   const bool q_ok = my_q < p.S;
   const size_t sidx = ((size_t)s * p.h + head) * p.S + (q_ok ? my_q : 0);
   float dsum;
@@ -600,7 +606,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_Q) void attn_bwd_dq_ke
     kvst.store(Ks, 1.0f, Vs, PQ, tid);
     if (kv0 + KB < p.S) load_kv(kv0 + KB);
     __syncthreads();
-    const bool full_tile = !causal && (!FEAT || p.kpm == nullptr) && kv0 + KB <= p.S;
+    const bool full_tile = !causal && (!FEAT || (p.kpm == nullptr && p.bias == nullptr)) && kv0 + KB <= p.S;
 
     f32x16_t sacc[KB / 32], dpacc[KB / 32];
 #pragma unroll
@@ -634,7 +640,9 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_Q) void attn_bwd_dq_ke
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool hide = !q_ok || dead[e] != 0 || (causal && key0 + e > my_q);
-            sacc[f][4 * i + e] = hide ? -INFINITY : sacc[f][4 * i + e];  // exp2 -> 0
+            float sv = sacc[f][4 * i + e];
+            if (FEAT && bias_row != nullptr && key0 + e < p.S) sv += bias_row[key0 + e] * kLog2e;
+            sacc[f][4 * i + e] = hide ? -INFINITY : sv;  // exp2 -> 0
           }
         }
     }
@@ -752,6 +760,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_K) void attn_bwd_dkv_k
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const int my_key = k0 + (lane & 31);
   const bool key_dead = key_dead_flag<FEAT>(p, s, my_key) != 0;
+  const float* bias_col = (FEAT && p.bias != nullptr && my_key < p.S) ? p.bias + (size_t)s * p.bias_stride + my_key : nullptr;
 
   while (qb_next < p.S) {
     const int qb0 = qb_next;
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_K) void attn_bwd_dkv_k
     if (qb_next < p.S) load_q(qb_next);  // next query tile (+ its statistics) in flight during this tile's math
     __syncthreads();
 
-    const bool full_tile = !causal && (!FEAT || p.kpm == nullptr) && qb0 + QB <= p.S && k0 + 32 <= p.S;
+    const bool full_tile = !causal && (!FEAT || (p.kpm == nullptr && p.bias == nullptr)) && qb0 + QB <= p.S && k0 + 32 <= p.S;
 
     f32x16_t sacc = acc_zero(), dpacc = acc_zero();
 #pragma unroll
@@ -782,7 +791,9 @@ __global__ __launch_bounds__(64 * NW, FEAT ? 2 : ATTN_WPE_K) void attn_bwd_dkv_k
       for (int r = 0; r < 16; ++r) {
         const int q = qb0 + acc_row(r, lane);
         const bool hide = key_dead || q >= p.S || (causal && my_key > q);
-        sacc[r] = hide ? -INFINITY : sacc[r];  // exp2 -> 0
+        float sv = sacc[r];
+        if (FEAT && bias_col != nullptr && q < p.S) sv += bias_col[(size_t)q * p.S] * kLog2e;
+        sacc[r] = hide ? -INFINITY : sv;  // exp2 -> 0
       }
     }
     if (drop) {
@@ -867,6 +878,7 @@ static AttnParams make_params(const void* qkv, void* out, const void* dout, void
   p.map.ph = ph; p.map.pw = pw; p.map.n_w = n_w; p.map.H = H; p.map.W = W;
   p.scaling = scaling; p.causal = causal;
   p.drop_p = 0.f; p.seed = nullptr; p.stream_id = 0;
+  p.bias = nullptr; p.bias_stride = 0;
   return p;
 }
 
@@ -906,7 +918,7 @@ static int launch_attn_feat(int which, const AttnParams& p, hipStream_t st) {
 
 template <typename T, int CPK, int VEC, int NW>
 static int launch_attn(int which, const AttnParams& p, hipStream_t st) {
-  const bool feat = p.causal || p.kpm != nullptr || p.drop_p > 0.f;
+  const bool feat = p.causal || p.kpm != nullptr || p.drop_p > 0.f || p.bias != nullptr;
   return feat ? launch_attn_feat<T, CPK, VEC, NW, 1>(which, p, st) : launch_attn_feat<T, CPK, VEC, NW, 0>(which, p, st);
 }
 template <typename T, int CPK, int VEC>
@@ -962,6 +974,36 @@ extern "C" int cvh_attn_bwd_drop(int dtype, const void* qkv, const void* out, co
   p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
   hipStream_t st = (hipStream_t)stream;
   p.out = const_cast<void*>(out);  // the dQ kernel forms D = rowsum(dO * O) itself
+  int rc = dispatch_attn(dtype, K_DQ, p, st);
+  if (rc) return rc;
+  return dispatch_attn(dtype, K_DKV, p, st);
+}
+
+/* general additive attention mask (multi_head_attention.py:197-208): bias [S][S] (bias_stride 0) or [nseq][S][S] float32 */
+extern "C" int cvh_attn_fwd_mask(int dtype, const void* qkv, void* out, float* lse, const unsigned char* kpm, const float* bias,
+                                 long long bias_stride, int nseq, int S, int h, int c, int ph, int pw, int n_w, int H, int W, float scaling,
+                                 int causal, float drop_p, const unsigned long long* seed, unsigned int stream_id, void* stream) {
+  if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && seed == nullptr)) return -2;
+  if (bias_stride != 0 && bias_stride < (long long)S * S) return -2;
+  AttnParams p = make_params(qkv, out, nullptr, nullptr, lse, nullptr, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
+  p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
+  p.bias = bias; p.bias_stride = bias_stride;
+  return dispatch_attn(dtype, K_FWD, p, (hipStream_t)stream);
+}
+
+extern "C" int cvh_attn_bwd_mask(int dtype, const void* qkv, const void* out, const void* dout, void* dqkv, const float* lse, float* dsum,
+                                 const unsigned char* kpm, const float* bias, long long bias_stride, int nseq, int S, int h, int c, int ph,
+                                 int pw, int n_w, int H, int W, float scaling, int causal, float drop_p, const unsigned long long* seed,
+                                 unsigned int stream_id, void* stream) {
+  if (c > 64 || c <= 0 || S <= 0 || S > 4096) return -2;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && seed == nullptr)) return -2;
+  if (bias_stride != 0 && bias_stride < (long long)S * S) return -2;
+  AttnParams p = make_params(qkv, nullptr, dout, dqkv, const_cast<float*>(lse), dsum, kpm, nseq, S, h, c, ph, pw, n_w, H, W, scaling, causal);
+  p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
+  p.bias = bias; p.bias_stride = bias_stride;
+  hipStream_t st = (hipStream_t)stream;
+  p.out = const_cast<void*>(out);
   int rc = dispatch_attn(dtype, K_DQ, p, st);
   if (rc) return rc;
   return dispatch_attn(dtype, K_DKV, p, st);

@@ -123,6 +123,8 @@ SIGNATURES = {
     "cvh_attn_bwd": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P],
     "cvh_attn_fwd_drop": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
     "cvh_attn_bwd_drop": [I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
+    "cvh_attn_fwd_mask": [I, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
+    "cvh_attn_bwd_mask": [I, P, P, P, P, P, P, P, P, L, I, I, I, I, I, I, I, I, I, F, I, F, P, U, P],
     "cvh_comm_available": [],
     "cvh_comm_unique_id": [P],
     "cvh_comm_init": [P, I, I, P],

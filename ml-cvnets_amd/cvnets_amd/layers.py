@@ -589,12 +589,12 @@ class MultiHeadAttention(nn.Module):
         return "{}(head_dim={}, num_heads={}, attn_dropout={})".format(self.__class__.__name__, self.head_dim, self.num_heads, self.attn_dropout.p)
 
     def forward_tokens(self, x2d: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None, out_drop_p: float = 0.0,
-                       residual: Optional[Tensor] = None) -> Tensor:
+                       residual: Optional[Tensor] = None, attn_bias: Optional[Tensor] = None) -> Tensor:
         """qkv projection -> fused attention -> output projection (+dropout +residual in its epilogue)."""
         qkv = ops.linear(x2d, self.qkv_proj.weight, self.qkv_proj.bias)
         # attn_dropout (multi_head_attention.py:217-218) acts on the softmax output inside the fused kernel; the mask is regenerated in backward
         o = ops.attention(qkv, self.num_heads, seqmap, causal=causal, key_padding_mask=key_padding_mask,
-                          drop_p=float(self.attn_dropout.p) if self.training else 0.0)
+                          drop_p=float(self.attn_dropout.p) if self.training else 0.0, attn_bias=attn_bias)
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, drop_p=out_drop_p, residual=residual)
 
     def forward(self, x_q: Tensor, x_kv: Optional[Tensor] = None, key_padding_mask: Optional[Tensor] = None,
@@ -612,13 +612,13 @@ class MultiHeadAttention(nn.Module):
             # model takes)
             x_q = x_q.transpose(0, 1)
         b, s, c = x_q.shape
-        causal = False
+        causal, bias = False, None
         if attn_mask is not None:
-            causal = _mask_is_causal(attn_mask, b, s, allow_2d=seq_first)
+            causal, bias = _split_mask(attn_mask, b, s, s, allow_2d=seq_first)
         x2 = x_q.reshape(b * s, c)
         if x2.dtype != ops.compute_dtype():
             x2 = x2.to(ops.compute_dtype())
-        y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask)
+        y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask, attn_bias=bias)
         y = y.view(b, s, -1)
         return y.transpose(0, 1) if seq_first else y
 
@@ -629,10 +629,14 @@ def _cross_attention(self, x_q: Tensor, x_kv: Tensor, key_padding_mask: Optional
     pieces rather than given kernels of its own: two projection GEMMs, the packed [q | k | v] matrix the fused attention kernels take
     (column layout identical to self-attention), both sequences padded to L = max(S, T) with the padded keys marked dead in the key-padding
     table the kernels already honour; the concatenation / padding copies are torch plumbing and differentiate themselves."""
-    if attn_mask is not None:
-        raise NotImplementedError("an additive attention mask with cross-attention is not on the HIP hot path")
     b, s_len, c = x_q.shape
     t_len = x_kv.shape[1]
+    mask_bias = None
+    if attn_mask is not None:  # [N, S, T] additive mask (multi_head_attention.py:197-208), padded to the [L, L] square the kernels index
+        _, mask_bias = _split_mask(attn_mask, b, s_len, t_len, detect_causal=False)
+        Lm = max(s_len, t_len)
+        if mask_bias.shape[-2] != Lm or mask_bias.shape[-1] != Lm:
+            mask_bias = torch.nn.functional.pad(mask_bias, (0, Lm - t_len, 0, Lm - s_len))  # plumbing; padded keys are dead, padded queries dropped
     if x_kv.shape[0] != b or x_kv.shape[2] != c:
         raise AssertionError(f"x_kv must be [{b}, T, {c}]. Got: {list(x_kv.shape)}")
     dt, d = ops.compute_dtype(), self.embed_dim
@@ -655,7 +659,7 @@ def _cross_attention(self, x_q: Tensor, x_kv: Tensor, key_padding_mask: Optional
         kpm = dead
     qkv = torch.cat([q3, kv3], dim=-1).reshape(b * L, 3 * d)  # plumbing
     o = ops.attention(qkv, self.num_heads, (b, L, 1, 1, L, 1, L), causal=False, key_padding_mask=kpm,
-                      drop_p=float(self.attn_dropout.p) if self.training else 0.0)
+                      drop_p=float(self.attn_dropout.p) if self.training else 0.0, attn_bias=mask_bias)
     o = o.view(b, L, d)[:, :s_len].reshape(b * s_len, d)
     return ops.linear(o.contiguous(), self.out_proj.weight, self.out_proj.bias).view(b, s_len, -1)
 
@@ -663,16 +667,21 @@ def _cross_attention(self, x_q: Tensor, x_kv: Tensor, key_padding_mask: Optional
 MultiHeadAttention._forward_cross = _cross_attention
 
 
-def _mask_is_causal(attn_mask: Tensor, b: int, s: int, allow_2d: bool = False) -> bool:
-    """The only additive mask on the reference's path is the CLIP text tower's causal mask
-    (cvnets/text_encoders/transformer.py:343-352); it is generated in-kernel.  Anything else is rejected.  (`allow_2d`: the [S, S] form
-    F.multi_head_attention_forward takes.)"""
-    if allow_2d and list(attn_mask.shape) == [s, s]:
-        attn_mask = attn_mask[None]
-    elif list(attn_mask.shape) != [b, s, s]:
-        raise AssertionError(f"Shape of attention mask should be [{b}, {s}, {s}]. Got: {attn_mask.shape}")
-    m = attn_mask[0]
-    ref = torch.full((s, s), float("-inf"), device=m.device, dtype=m.dtype).triu(1)
-    if not torch.equal(m, ref):
-        raise NotImplementedError("only the causal additive attention mask is on the HIP hot path")
-    return True
+def _split_mask(attn_mask: Tensor, b: int, s: int, t: int, allow_2d: bool = False, detect_causal: bool = True):
+    """(causal, bias) for an additive attention mask [N, S, T] (multi_head_attention.py:197-208; `allow_2d`: the [S, S] form
+    F.multi_head_attention_forward takes, boolean masks included).  The CLIP text tower's causal mask
+    (cvnets/text_encoders/transformer.py:343-352) is recognised and GENERATED in-kernel (no mask traffic); any other mask is handed to the
+    kernels as a float32 bias tile source."""
+    if allow_2d and list(attn_mask.shape) == [s, t]:
+        m = attn_mask
+    elif list(attn_mask.shape) == [b, s, t]:
+        m = attn_mask
+    else:
+        raise AssertionError(f"Shape of attention mask should be [{b}, {s}, {t}]. Got: {attn_mask.shape}")
+    if m.dtype == torch.bool:
+        m = torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill(m, float("-inf"))
+    if detect_causal and s == t:
+        ref = torch.full((s, s), float("-inf"), device=m.device, dtype=m.dtype).triu(1)
+        if torch.equal(m, ref.expand_as(m)):
+            return True, None
+    return False, m.to(torch.float32)

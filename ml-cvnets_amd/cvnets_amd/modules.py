@@ -154,7 +154,8 @@ class TransformerEncoder(nn.Module):
             self.__class__.__name__, self.embed_dim, self.ffn_dim, self.std_dropout, self.ffn_dropout, self.stochastic_dropout,
             self.attn_fn_name, self.act_fn_name, self.norm_type)
 
-    def forward_tokens(self, x: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    def forward_tokens(self, x: Tensor, seqmap, causal: bool = False, key_padding_mask: Optional[Tensor] = None,
+                       attn_bias: Optional[Tensor] = None) -> Tensor:
         ln1, mha, drop1 = self.pre_norm_mha[0], self.pre_norm_mha[1], self.pre_norm_mha[2]
         if not isinstance(ln1, nn.LayerNorm):
             raise NotImplementedError("transformer_norm_layer must be layer_norm on the HIP hot path")
@@ -164,12 +165,13 @@ class TransformerEncoder(nn.Module):
             # x = x + StochasticDepth(Dropout(branch(LN(x)))): one Bernoulli draw per sample scales the whole branch; the residual add rides in
             # the drop-path kernel instead of the GEMM epilogue (transformer.py:140-155)
             y = ops.layer_norm_tokens(x, ln1, seqmap)
-            x = ops.drop_path(mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1), x, sd, True, seqmap)
+            x = ops.drop_path(mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, attn_bias=attn_bias), x, sd,
+                              True, seqmap)
             return self._ffn_tokens(x, seqmap, sd)
         # x = x + Dropout(MHA(LN(x)))   — dropout and residual live in the out_proj GEMM epilogue; the fork x -> (x, LN(x)) is one autograd
         # node, so the two gradients of x meet inside the LayerNorm backward kernel
         x, y = ops.layer_norm_fork(x, ln1, seqmap)
-        x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x)
+        x = mha.forward_tokens(y, seqmap, causal=causal, key_padding_mask=key_padding_mask, out_drop_p=p1, residual=x, attn_bias=attn_bias)
         return self._ffn_tokens(x, seqmap, 0.0)
 
     def _ffn_tokens(self, x: Tensor, seqmap, sd: float) -> Tensor:
@@ -221,14 +223,14 @@ class TransformerEncoder(nn.Module):
         if x_prev is not None:
             return self._forward_cross(x, x_prev, key_padding_mask, attn_mask)
         b, s, c = x.shape
-        causal = False
+        causal, bias = False, None
         if attn_mask is not None:
-            from .layers import _mask_is_causal
-            causal = _mask_is_causal(attn_mask, b, s)
+            from .layers import _split_mask
+            causal, bias = _split_mask(attn_mask, b, s, s)  # the causal triangle is generated in-kernel, any other mask becomes a bias source
         x2 = x.reshape(b * s, c)
         if x2.dtype != ops.compute_dtype():
             x2 = x2.to(ops.compute_dtype())
-        y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask)
+        y = self.forward_tokens(x2.contiguous(), (b, s, 1, 1, s, 1, s), causal=causal, key_padding_mask=key_padding_mask, attn_bias=bias)
         return y.view(b, s, c)
 
 

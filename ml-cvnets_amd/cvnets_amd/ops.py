@@ -1183,7 +1183,7 @@ class AttentionFn(torch.autograd.Function):
     projections; `seqmap` = (nseq, S, ph, pw, n_w, H, W) realises MobileViTBlock.unfolding/folding by addressing."""
 
     @staticmethod
-    def forward(ctx, qkv, kpm, cfg):
+    def forward(ctx, qkv, kpm, bias, cfg):
         heads, seqmap, causal, drop_p, stream_id = cfg
         nseq, S, ph, pw, n_w, H, W = seqmap
         _check_dev(qkv)
@@ -1195,37 +1195,47 @@ class AttentionFn(torch.autograd.Function):
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
         lse = _f32(nseq * heads * S, qkv.device)
         seed = dropout_seed(qkv.device) if drop_p > 0 else None  # the backward regenerates the keep mask from the same seed / stream id
-        _lib.call("cvh_attn_fwd_drop", _dt(qkv), _p(qkv), _p(out), _p(lse), _p(kpm), nseq, S, heads, c, ph, pw, n_w, H, W, float(c) ** -0.5,
-                  1 if causal else 0, float(drop_p), _p(seed), stream_id, _stream())
+        bstride = 0
+        if bias is not None:  # additive mask [S, S] (shared) or [nseq, S, S], float32 (multi_head_attention.py:197-208)
+            if bias.dtype != torch.float32 or not bias.is_contiguous() or tuple(bias.shape) not in ((S, S), (nseq, S, S)):
+                raise RuntimeError(f"attention bias must be contiguous float32 [{S}, {S}] or [{nseq}, {S}, {S}]")
+            bstride = S * S if bias.dim() == 3 else 0
+        _lib.call("cvh_attn_fwd_mask", _dt(qkv), _p(qkv), _p(out), _p(lse), _p(kpm), _p(bias), bstride, nseq, S, heads, c, ph, pw, n_w, H, W,
+                  float(c) ** -0.5, 1 if causal else 0, float(drop_p), _p(seed), stream_id, _stream())
         ctx.cfg = cfg
         ctx.seed = seed
-        ctx.save_for_backward(qkv, out, lse, kpm)
+        ctx.bstride = bstride
+        ctx.save_for_backward(qkv, out, lse, kpm, bias)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         heads, seqmap, causal, drop_p, stream_id = ctx.cfg
         nseq, S, ph, pw, n_w, H, W = seqmap
-        qkv, out, lse, kpm = ctx.saved_tensors
+        qkv, out, lse, kpm, bias = ctx.saved_tensors
         d = qkv.shape[1] // 3
         c = d // heads
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         dsum = _f32(nseq * heads * S, qkv.device)
-        _lib.call("cvh_attn_bwd_drop", _dt(qkv), _p(qkv), _p(out), _p(dout), _p(dqkv), _p(lse), _p(dsum), _p(kpm), nseq, S, heads, c, ph, pw, n_w,
-                  H, W, float(c) ** -0.5, 1 if causal else 0, float(drop_p), _p(ctx.seed), stream_id, _stream())
-        return dqkv, None, None
+        _lib.call("cvh_attn_bwd_mask", _dt(qkv), _p(qkv), _p(out), _p(dout), _p(dqkv), _p(lse), _p(dsum), _p(kpm), _p(bias), ctx.bstride, nseq, S,
+                  heads, c, ph, pw, n_w, H, W, float(c) ** -0.5, 1 if causal else 0, float(drop_p), _p(ctx.seed), stream_id, _stream())
+        return dqkv, None, None, None
 
 
 def attention(qkv2d, heads: int, seqmap: Tuple[int, ...], causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None,
-              drop_p: float = 0.0):
-    """drop_p > 0: dropout on the attention probabilities (the caller passes it in training mode only), mask regenerated in backward"""
+              drop_p: float = 0.0, attn_bias: Optional[torch.Tensor] = None):
+    """drop_p > 0: dropout on the attention probabilities (the caller passes it in training mode only), mask regenerated in backward.
+    attn_bias: additive mask [S, S] or [nseq, S, S] (added to the scaled scores before the softmax; a constant: no gradient)."""
     kpm = None
     if key_padding_mask is not None:
         kpm = (key_padding_mask != 0).to(torch.uint8).contiguous()  # plumbing; any non-zero entry (True, 1, -inf) masks the key, as .to(torch.bool) does in the reference
+    bias = None
+    if attn_bias is not None:
+        bias = attn_bias.detach().to(torch.float32).contiguous()  # plumbing
     sid = next_stream_id() if drop_p > 0 else 0
     _trace_site("attention", sid, drop_p, qkv2d.shape)
-    return AttentionFn.apply(qkv2d, kpm, (int(heads), tuple(int(v) for v in seqmap), bool(causal), float(drop_p), sid))
+    return AttentionFn.apply(qkv2d, kpm, bias, (int(heads), tuple(int(v) for v in seqmap), bool(causal), float(drop_p), sid))
 
 
 # ------------------------------------------------------------------------------------------------

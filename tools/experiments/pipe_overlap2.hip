@@ -6,6 +6,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 constexpr int NM = 8, NV = 32;
+__device__ unsigned long long g_cycles;
 // CLS 0: v_fma_f32, 1: v_pk_fma_f32, 2: v_exp_f32, 3: v_cvt_pk_bf16_f32, 4: v_pk_mul_f32, 5: v_add_u32 (int), 6: v_rcp
 template <int CLS, bool DOM, bool DOV> __global__ __launch_bounds__(256) void k(float* out, int iters) {
   const int lane = threadIdx.x & 63;
@@ -13,6 +14,7 @@ template <int CLS, bool DOM, bool DOV> __global__ __launch_bounds__(256) void k(
   f32x4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   f32x2_t p[8]; float t[8]; unsigned u[8];
   for (int i = 0; i < 8; ++i) { p[i] = f32x2_t{lane * 0.001f + i, 0.5f}; t[i] = 0.1f * i + lane * 1e-3f; u[i] = lane + i; }
+  const unsigned long long c0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (DOM) {
 #pragma unroll
@@ -33,10 +35,12 @@ template <int CLS, bool DOM, bool DOV> __global__ __launch_bounds__(256) void k(
         }
     }
   }
+  const unsigned long long c1 = __builtin_readcyclecounter();
   float s = 0;
   for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   for (int i = 0; i < 8; ++i) s += p[i][0] + p[i][1] + t[i] + (float)u[i];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_cycles = c1 - c0;
 }
 template <int CLS> __global__ __launch_bounds__(256) void ks(float* out, int iters) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,6 +86,8 @@ template <int CLS, bool DOM, bool DOV> float run1(float* out, int wps) {
   k<CLS, DOM, DOV><<<grid, 256>>>(out, 10); (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0); k<CLS, DOM, DOV><<<grid, 256>>>(out, iters); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long cyc = 0; (void)hipMemcpyFromSymbol(&cyc, HIP_SYMBOL(g_cycles), sizeof(cyc));
+  printf("      [CLS %d M %d V %d w%d: %.1f us, shader-clock cycles of wave 0: %.1f per iteration -> clock %.2f GHz]\n", CLS, (int)DOM, (int)DOV, wps, ms * 1e3, (double)cyc / iters, (double)cyc / (ms * 1e-3) * 1e-9);
   return ms * 1e-3 * 2.4e9 / ((double)iters * wps);
 }
 template <int CLS> void run(const char* name, float* out) {

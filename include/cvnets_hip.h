@@ -136,6 +136,13 @@ int cvh_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, co
                       float* invstd, float* scale, float* shift, void* stream);
 int cvh_bn_apply(int dtype, const void* x, const float* scale, const float* shift, int act, const void* residual, void* y,
                  long long rows, int C, void* stream);
+/* cvh_bn_apply that ALSO emits what the next InvertedResidual block needs of its input (csrc/bngram.hip; bf16, C in {16, 32, 64}):
+ * gram_s[C*C + C] = G = y^T y (full symmetric [C][C]) followed by s = 1^T y, of the values as stored, from the same pass — instead of a
+ * second read of y by cvh_gemm_dw(y, y) + cvh_colsum (cvnets/modules/mobilenetv2.py:231-235 feeding the next block's :180-207).
+ * part = float[R * (C*C + C)] scratch, R = cvh_bn_apply_gram_rows(rows, C) (0: not covered, use the separate entry points). */
+int cvh_bn_apply_gram_rows(long long rows, int C);
+int cvh_bn_apply_gram(int dtype, const void* x, const float* scale, const float* shift, int act, const void* residual, void* y,
+                      long long rows, int C, float* part, int R, float* gram_s, void* stream);
 int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int act, long long rows, int C, float* part, void* stream);
 int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,

@@ -63,6 +63,8 @@ SIGNATURES = {
     "cvh_bn_finalize": [P, I, I, D, P, P, P, P, F, F, P, P, P, P, P],
     "cvh_bn_eval_coeff": [P, P, P, P, F, I, P, P, P, P, P],
     "cvh_bn_apply": [I, P, P, P, I, P, P, L, I, P],
+    "cvh_bn_apply_gram_rows": [L, I],
+    "cvh_bn_apply_gram": [I, P, P, P, I, P, P, L, I, P, I, P, P],
     "cvh_bn_bwd_reduce": [I, P, P, P, P, P, P, I, L, I, P, P],
     "cvh_bn_bwd_finalize": [P, I, I, D, P, P, P, I, I, P, P, P, P, P, P],
     "cvh_bn_bwd_apply": [I, P, P, P, P, I, P, P, P, P, L, I, P],

@@ -165,7 +165,7 @@ def _linear_bn_weight_grad(g, x, weight, coef, M, N, Kp, P_ready=None, gram=None
 
 class InvertedResidualFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg, xsum=None):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, wd, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, cfg, xsum=None, gram_in=None):
         stride, use_res, training, act1, act2, mom, eps = cfg
         ops._check_dev(x)
         B, Cin, H, W = x.shape
@@ -192,7 +192,8 @@ class InvertedResidualFn(torch.autograd.Function):
             # in x), expansion + BN + act + depthwise conv in one kernel (csrc/dwx.hip)
             y1 = None
             if training:
-                gram = _gram(x, M1, Cin, s_known=xsum)
+                # G = x^T x, 1^T x: formed by the producer of x in its BatchNorm-apply pass (ops._bn_apply_out) or by a pass over x here
+                gram = (gram_in[:Cin * Cin], gram_in[Cin * Cin:]) if gram_in is not None else _gram(x, M1, Cin, s_known=xsum)
                 part = _f32(2 * hid, dev)
                 _lib.call("cvh_gram_bn_stats", _p(gram[0]), _p(gram[1]), _p(wp1), _p(part), hid, Cin, Cin, _stream())
                 st1 = ops._bn_forward(x, M1, hid, part, 1, g1, b1, rm1, rv1, True, mom[0], eps[0])
@@ -225,20 +226,22 @@ class InvertedResidualFn(torch.autograd.Function):
         if training:
             st3 = ops._bn_forward(y3, M2, Cout, part, R, g3, b3, rm3, rv3, True, mom[2], eps[2])
         out = ops.nhwc_empty(B, Cout, Ho, Wo, dt, dev)
-        _lib.call("cvh_bn_apply", _dt(y3), _p(y3), _p(st3[2]), _p(st3[3]), ACT_NONE, _p(x if use_res else None), _p(out), M2, Cout,
-                  _stream())
+        gs = ops._bn_apply_out(y3, st3, ACT_NONE, x if use_res else None, out, M2, Cout, g3, training)
         ctx.cfg = cfg
         ctx.geom = (B, Cin, H, W, Ho, Wo, hid, Cout)
         ctx.params = (g1, b1, g2, b2, g3, b3)
         # column sums of the block OUTPUT for the next block's statistics, without a pass over it: the output is a train-mode BatchNorm
         # (+ the input on the residual path), so 1^T out = rows * beta3 (+ 1^T x).  (bf16 rounding of the stored output is zero-mean noise.)
         osum = None
-        if use_x and training and (not use_res or gram is not None):
+        if gs is None and use_x and training and (not use_res or gram is not None):
             osum = _f32(Cout, dev)
             _lib.call("cvh_axpb", _p(b3), float(M2), _p(gram[1]) if use_res else None, _p(osum), Cout, _stream())
         ctx.has_osum = osum is not None
         ctx.use_x = use_x
         ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, *(gram if gram is not None else (None, None)))
+        if gs is not None:
+            ctx.mark_non_differentiable(gs)
+            return out, None, gs
         if osum is not None:
             ctx.mark_non_differentiable(osum)
             return out, osum
@@ -330,7 +333,7 @@ class InvertedResidualFn(torch.autograd.Function):
         elif use_res:
             dx = dout
         dw1 = _linear_bn_weight_grad(g1t, x, w1, coef1, M1, hid, Cin, P_ready=P1, gram=gram)
-        return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None, None)
+        return (dx, dw1, dg1, db1, None, None, dwd, dg2, db2, None, None, dw3, dg3, db3, None, None, None, None, None)
 
 
 def inverted_residual(x, exp, dw, red, *, stride: int, use_res: bool):
@@ -347,10 +350,16 @@ def inverted_residual(x, exp, dw, red, *, stride: int, use_res: bool):
         osum0, ver0, ptr0 = tag
         if ver0 == x._version and ptr0 == x.data_ptr() and osum0.numel() == x.shape[1] and osum0.device == x.device:
             xsum = osum0
+    gram_in = None
+    if x.is_cuda and _dwx_eligible(x.dtype, x.shape[1], c1.weight, c1.weight.shape[0], int(stride), int(a1)):
+        gram_in = ops.gram_of_input(x, x.shape[1], training)
     res = InvertedResidualFn.apply(x, c1.weight, n1.weight, n1.bias, n1.running_mean, n1.running_var, cd.weight, n2.weight, n2.bias,
-                                   n2.running_mean, n2.running_var, c3.weight, n3.weight, n3.bias, n3.running_mean, n3.running_var, cfg, xsum)
+                                   n2.running_mean, n2.running_var, c3.weight, n3.weight, n3.bias, n3.running_mean, n3.running_var, cfg, xsum,
+                                   gram_in)
+    if isinstance(res, tuple) and len(res) == 3:  # (out, None, G | s): the apply pass of the block output formed the next block's Gram matrix
+        return ops.tag_producer((res[0], res[2]), n3.weight)
     if isinstance(res, tuple):
         out, osum = res
         out._cvh_colsum = (osum, out._version, out.data_ptr())
-        return out
-    return res
+        return ops.tag_producer(out, n3.weight)
+    return ops.tag_producer(res, n3.weight)

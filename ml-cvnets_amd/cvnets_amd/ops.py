@@ -645,6 +645,58 @@ def _bn_forward(y, rows, C, part, R, gamma, beta, rmean, rvar, training, momentu
     return stats
 
 
+# ------------------------------------------------------------------------------------------------
+# BatchNorm apply that also serves the NEXT fused InvertedResidual block (csrc/bngram.hip)
+# ------------------------------------------------------------------------------------------------
+# A fused InvertedResidual block starts from the Gram matrix G = x^T x and the column sums of its narrow input (the statistics of its
+# expansion BatchNorm follow from them, fused.py).  The producer of that input — the BatchNorm apply of the previous block / the stem /
+# a ConvLayer2d — can form both in the pass that writes the tensor.  Who consumes a layer's output is not known to the layer, so it is
+# LEARNED: every such producer tags its output with the BatchNorm weight it used (`_cvh_src`); a fused block that receives a tagged input
+# without a Gram matrix sets `_cvh_gram_wanted` on that parameter, and from the next forward on the producer's apply pass emits it
+# (`_cvh_gram` on the output: (G | s) float32 [C*C + C], tensor version, address — dropped after any in-place modification).
+_GRAM_OUT = os.environ.get("CVH_GRAM_OUT", "1") != "0"
+
+
+def _bn_apply_out(y, stats, act, residual, out, rows, C, src, training):
+    """cvh_bn_apply into `out`; returns the (G | s) tensor when the pass also formed it, else None"""
+    if (_GRAM_OUT and training and src is not None and getattr(src, "_cvh_gram_wanted", False) and y.dtype == torch.bfloat16):
+        R = _lib.query("cvh_bn_apply_gram_rows", int(rows), int(C))
+        if R > 0:
+            n = C * C + C
+            part = _f32(R * n, y.device)
+            gs = _f32(n, y.device)
+            _lib.call("cvh_bn_apply_gram", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, _p(residual), _p(out), rows, C, _p(part), R, _p(gs),
+                      _stream())
+            return gs
+    _lib.call("cvh_bn_apply", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, _p(residual), _p(out), rows, C, _stream())
+    return None
+
+
+def tag_producer(res, src):
+    """res = `out` or (out, gs) as returned by a producer's autograd function: attach the tags, return out"""
+    out, gs = res if isinstance(res, tuple) else (res, None)
+    if src is not None and _GRAM_OUT:
+        out._cvh_src = src
+        if gs is not None:
+            out._cvh_gram = (gs, out._version, out.data_ptr())
+    return out
+
+
+def gram_of_input(x, C, training):
+    """the (G | s) tensor a producer attached to x, if still valid; otherwise ask the producer for it from the next step on"""
+    if not (_GRAM_OUT and training):
+        return None
+    tag = getattr(x, "_cvh_gram", None)
+    if tag is not None:
+        gs, ver, ptr = tag
+        if ver == x._version and ptr == x.data_ptr() and gs.numel() == C * C + C and gs.device == x.device:
+            return gs
+    src = getattr(x, "_cvh_src", None)
+    if src is not None and x.dtype == torch.bfloat16:
+        src._cvh_gram_wanted = True
+    return None
+
+
 def _bn_backward_coeffs(y, dout, stats, gamma, act, rows, C, training, beta=None):
     """The statistics half of the BatchNorm backward: returns (coeff[3][C], dgamma, dbeta) with dy_raw = coeff[0] * (dout * act'(bn(y))) +
     coeff[1] * y + coeff[2] left to the consumer (cvh_bn_bwd_apply, or an operand load that forms it: csrc/ir_pb.hip)."""
@@ -711,8 +763,11 @@ class ConvBNAct(torch.autograd.Function):
             _conv_gemm(x, x2, C1, C2, wp, y, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, bias=bias, stats_part=part)
             stats = _bn_forward(y, M, Cout, part, R, gamma, beta, rmean, rvar, training, momentum, eps)
             out = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
-            _lib.call("cvh_bn_apply", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, _p(residual), _p(out), M, Cout, _stream())
+            gs = _bn_apply_out(y, stats, act, residual, out, M, Cout, gamma, training)
             ctx.save_for_backward(x, x2, weight, y, stats, gamma)
+            if gs is not None:
+                ctx.mark_non_differentiable(gs)
+                return out, gs
             return out
         pre = nhwc_empty(B, Cout, Ho, Wo, dtype, dev) if act != ACT_NONE else None
         _conv_gemm(x, x2, C1, C2, wp, y, B, H, W, Ho, Wo, KH, KW, stride, pad, dil, Cout, bias=bias, act=act, save_pre=pre, residual=residual)
@@ -720,7 +775,7 @@ class ConvBNAct(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         stride, pad, dil, act, use_bn, training, momentum, eps = ctx.cfg
         B, C1, C2, H, W, Ho, Wo, Cout, Cin_real, KH, KW = ctx.shapes
         x, x2, weight, y, stats, gamma = ctx.saved_tensors
@@ -772,7 +827,7 @@ class ConvBNAct(torch.autograd.Function):
 def conv_bn_act(x, weight, bias=None, gamma=None, beta=None, rmean=None, rvar=None, *, stride=1, pad=0, dil=1, act=ACT_NONE,
                 use_bn=False, training=True, momentum=0.1, eps=1e-5, residual=None, x2=None):
     cfg = (int(stride), int(pad), int(dil), int(act), bool(use_bn), bool(training), float(momentum), float(eps))
-    return ConvBNAct.apply(x, x2, weight, bias, gamma, beta, rmean, rvar, residual, cfg)
+    return tag_producer(ConvBNAct.apply(x, x2, weight, bias, gamma, beta, rmean, rvar, residual, cfg), gamma if use_bn else None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -814,14 +869,17 @@ class StemConvBNAct(torch.autograd.Function):
         _lib.call("cvh_stem_conv_fwd", _dt(x), _p(x), _dt(weight), _p(weight), _p(y), _p(part), B, H, W, Cout, _stream())
         stats = _bn_forward(y, M, Cout, part, R, gamma, beta, rmean, rvar, training, momentum, eps)
         out = nhwc_empty(B, Cout, Ho, Wo, dtype, dev)
-        _lib.call("cvh_bn_apply", _dt(y), _p(y), _p(stats[2]), _p(stats[3]), act, None, _p(out), M, Cout, _stream())
+        gs = _bn_apply_out(y, stats, act, None, out, M, Cout, gamma, training)
         ctx.cfg = cfg
         ctx.beta = beta
         ctx.save_for_backward(x, weight, y, stats, gamma)
+        if gs is not None:
+            ctx.mark_non_differentiable(gs)
+            return out, gs
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         act, training, momentum, eps = ctx.cfg
         x, weight, y, stats, gamma = ctx.saved_tensors
         B, _, H, W = x.shape
@@ -843,7 +901,7 @@ class StemConvBNAct(torch.autograd.Function):
 
 
 def stem_conv_bn_act(x, weight, gamma, beta, rmean, rvar, *, act=ACT_NONE, training=True, momentum=0.1, eps=1e-5):
-    return StemConvBNAct.apply(x, weight, gamma, beta, rmean, rvar, (int(act), bool(training), float(momentum), float(eps)))
+    return tag_producer(StemConvBNAct.apply(x, weight, gamma, beta, rmean, rvar, (int(act), bool(training), float(momentum), float(eps))), gamma)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -178,7 +178,7 @@ def test_temporal_block_host_composition_against_the_oracle(monkeypatch):
             y = y + residual
         return (y, pre) if expose_pre else y  # (in_pre / in_act only steer the fused backward: the input is already the activated tensor)
 
-    def attention(qkv, heads, seqmap, causal=False, key_padding_mask=None, drop_p=0.0):
+    def attention(qkv, heads, seqmap, causal=False, key_padding_mask=None, drop_p=0.0, attn_bias=None):
         b, L = seqmap[0], seqmap[1]
         assert tuple(seqmap[2:]) == (1, 1, L, 1, L) and not causal and drop_p == 0.0
         d = qkv.shape[1] // 3
@@ -186,6 +186,8 @@ def test_temporal_block_host_composition_against_the_oracle(monkeypatch):
         a = (q * (d // heads) ** -0.5) @ k.transpose(-1, -2)
         if key_padding_mask is not None:
             a = a.masked_fill(key_padding_mask.bool()[:, None, None, :], float("-inf"))
+        if attn_bias is not None:
+            a = a + (attn_bias if attn_bias.dim() == 2 else attn_bias[:, None])
         return (torch.softmax(a, -1) @ v).transpose(1, 2).reshape(b * L, d)
 
     class TorchConv(torch.nn.Module):  # ConvLayer2d stand-in on NCHW tensors, same parameters

@@ -175,9 +175,7 @@ def test_unsupported_variants_fail_loudly():
         cvnets_amd.MobileViT(default_opts(**{"model.activation.name": "hard_swish"}))
     with pytest.raises(NotImplementedError):
         cvnets_amd.MobileViT(default_opts(**{"model.normalization.name": "group_norm"}))
-    m = cvnets_amd.MultiHeadAttention(64, 4).cuda()
-    with pytest.raises(NotImplementedError):  # (cross-attention itself runs since round 5: tests/test_variants_gpu.py; an additive mask with it does not)
-        m(torch.zeros(2, 8, 64, device="cuda"), x_kv=torch.zeros(2, 8, 64, device="cuda"), attn_mask=torch.zeros(2, 8, 8, device="cuda"))
+    # (cross-attention runs since round 5, an additive mask with it since round 6: tests/test_variants_gpu.py, tests/test_attn_mask_gpu.py)
 
 
 def test_inplace_param_grads_and_pack_plan_match_autograd_path():

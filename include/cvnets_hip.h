@@ -406,6 +406,13 @@ int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gam
  * x -> ... + x, cvnets/modules/transformer.py:139-155) joins inside this kernel instead of in a separate elementwise add */
 int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                           float* part, long long rows, int C, const void* dres, void* stream);
+/* cvh_layernorm_bwd_res that ALSO stores dxd = dx with the keep mask of the Dropout in front of this LayerNorm applied (x = res +
+ * Dropout(linear(h)), cvnets/modules/transformer.py:140-155): exactly cvh_dropout(dx) with (drop_p, seed, stream_id), from the same pass.
+ * cvh_ln_bwd_drop_ok(C) == 0: not covered for this width (call cvh_dropout on dx). */
+int cvh_ln_bwd_drop_ok(int C);
+int cvh_layernorm_bwd_res_drop(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                               float* part, long long rows, int C, const void* dres, void* dxd, float drop_p,
+                               const unsigned long long* seed, unsigned int stream_id, void* stream);
 int cvh_ln_bwd_rows(long long rows); /* rows of part[rows][2][C] (dgamma | dbeta) */
 
 /* ---- fused multi-head self-attention ------------------------------------------------------------ */

@@ -342,6 +342,20 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Workgroup barrier for kernels that keep global loads / stores in flight ACROSS it.  __syncthreads() is a fence + s_barrier, and for the fence
+// the compiler puts `s_waitcnt vmcnt(0)` in front of the barrier: every wave then drains ALL its outstanding global loads (a prefetch meant to
+// fly for several more stages) and — vmcnt counts them too on this target — all its result STORES at every barrier; found with
+// gemm_tn_rows_kernel, whose 3, 5 or 8 stages "in flight" all took the same time.  What such a barrier really has to order is LDS traffic between
+// the waves: a wave's LDS writes and reads issued before it are complete (lgkmcnt(0)); data that arrives in LDS by global_load_lds needs the
+// issuing wave's own (counted) s_waitcnt vmcnt in front of the call.  The "memory" clobber keeps the compiler from moving memory accesses across.
+// -DCVH_FENCED_BARRIERS restores __syncthreads() everywhere (A/B builds).
+__device__ __forceinline__ void wg_barrier_lds() {
+#ifdef CVH_FENCED_BARRIERS
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 // XCD-aware block remap (MI355X: block b runs on XCD b % 8, each XCD has its own L2): give every XCD one CONTIGUOUS chunk of the
 // logical work list so that neighbouring work items (which share halo rows / operand panels) hit the same L2.  Bijective for any n.
 __device__ __forceinline__ int xcd_chunk_id(int b, int n) {
@@ -430,7 +444,7 @@ __device__ __forceinline__ int seq_row(const SeqMap& m, int s, int n) {
 #define CVH_TUNE_BIG_MIN_N 16 /* narrowest output the ragged direct-to-LDS GEMM takes (0: the default, 192) */
 #define CVH_TUNE_NO_TN256 19 /* 1: the direct-to-LDS dW product stays on 128 x 128 tiles (gemm_big.hip: gemm_tn256_shape) */
 #define CVH_TUNE_GEMM_FILL 18 /* conv_gemm: narrow the N tile until the launch has at least this many workgroups (0: off) */
-#define CVH_TUNE_MAX 24
+#define CVH_TUNE_MAX 32
 int cvh_tune_get(int key);
 
 // host-side tally of a kernel family's launches and algorithmic bytes (cvh_family_counters; defined in gemm.hip)

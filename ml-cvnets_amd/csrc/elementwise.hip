@@ -904,7 +904,7 @@ __global__ void seed_advance_kernel(unsigned long long* seed) { *seed = *seed * 
 // =============================================================================================
 // C ABI
 // =============================================================================================
-static int g_tune[CVH_TUNE_MAX] = {0, /*TN_PITCH*/ 0, /*TN_WGS*/ 512, /*GEMM_GRID*/ 512, /*DW_XCD*/ 1, /*BIG_GEMM*/ 1, /*COLRED_ROWS*/ 1024, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, /*GEMM_FILL*/ 256, 0, 0, 0, 0, 0};
+static int g_tune[CVH_TUNE_MAX] = {0, /*TN_PITCH*/ 0, /*TN_WGS*/ 512, /*GEMM_GRID*/ 512, /*DW_XCD*/ 1, /*BIG_GEMM*/ 1, /*COLRED_ROWS*/ 1024, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, /*GEMM_FILL*/ 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 int cvh_tune_get(int key) { return (key > 0 && key < CVH_TUNE_MAX) ? g_tune[key] : 0; }
 extern "C" int cvh_set_tuning(int key, int value) {
   if (key <= 0 || key >= CVH_TUNE_MAX) return -2;

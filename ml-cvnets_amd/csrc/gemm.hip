@@ -212,6 +212,14 @@ static void tn_plan(int M, int N, int Ktot, int* out_tiles, int* k_tiles, int* s
     const int target_wgs = cvh_tune_get(CVH_TUNE_TN_WGS) * (*out_tiles >= 8 ? 2 : 1);
     sp = (target_wgs + *out_tiles - 1) / *out_tiles;
   }
+  TnRowsGeom rg;
+  if (tn_big_shape(M, N, Ktot) && cvh_tune_get(CVH_TUNE_BIG_GEMM) && !t256 && gemm_tn_rows_plan(M, N, Ktot, &rg)) {
+    // whole-row workgroups (gemm_rows.hip): one partial row per workgroup along M; a launch of this shape that kernel cannot take runs the
+    // tiled kernels on the same splits
+    *splits = rg.splits;
+    *mps = rg.m_per_split;
+    return;
+  }
   int max_splits = (M + 255) / 256;
   if (tn_skinny_shape(M, N, Ktot)) {  // gemm_tn_skinny_kernel: 4 partial rows per workgroup, >= 4 stages per wave
     const int wgs = cvh_tune_get(CVH_TUNE_SKINNY_WGS) > 0 ? cvh_tune_get(CVH_TUNE_SKINNY_WGS) : 512;
@@ -261,7 +269,7 @@ extern "C" long long cvh_gemm_dw_scratch_elems(int M, int N, int Ktot) {
 extern "C" int cvh_gemm_dw_folds_bias(int dtype, int M, int N, int Ktot) {
   // the direct-to-LDS kernel folds it only through a padded column of ones: needs K % 128 != 0 (gemm_big.hip)
   if (dtype == CVH_DT_BF16 && cvh_tune_get(CVH_TUNE_BIG_GEMM) && tn_big_shape(M, N, Ktot))
-    return gemm_tn256_shape(N, Ktot) ? 1 : ((Ktot % 128) != 0 ? 1 : 0);  // the 256 x 256 kernel sums the columns itself where K leaves no padded column
+    return (gemm_tn256_shape(N, Ktot) || gemm_tn_rows_plan(M, N, Ktot, nullptr)) ? 1 : ((Ktot % 128) != 0 ? 1 : 0);  // the 256 x 256 kernel sums the columns itself where K leaves no padded column
   return M > 0 ? 1 : 0;
 }
 
@@ -356,6 +364,9 @@ static int gemm_dw_run(int dtype, GemmTNParams p, int N, int KH, int KW, int C1,
     if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, 0, 1>), grid, dim3(256), 0, st, p);
     else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, 0, 1>), grid, dim3(256), 0, st, p);
     else return -1;
+  } else if (dtype == CVH_DT_BF16 && p.part != nullptr && cvh_tune_get(CVH_TUNE_BIG_GEMM) && !gemm_tn256_shape(p.N, p.Ktot) && gemm_tn_rows_eligible(p)) {
+    const int rc = launch_gemm_tn_rows(p, st);  // MobileViT-sized token linears under >= 128 k rows: whole rows per workgroup
+    if (rc) return rc;
   } else if (dtype == CVH_DT_BF16 && p.part != nullptr && gemm_tn_big_eligible(p)) {  // transformer-sized linears (ViT-B / CLIP)
     if (p.bias_part != nullptr && !gemm_tn256_shape(p.N, p.Ktot) && (p.Ktot % 128) == 0) return -2;  // cvh_gemm_dw_folds_bias() says so
     const int rc = launch_gemm_tn_big(p, splits, st);

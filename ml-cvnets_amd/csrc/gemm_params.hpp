@@ -60,6 +60,20 @@ int launch_gemm_tn_big(const GemmTNParams& p, int splits, hipStream_t st);
 bool gemm_big_eligible(const ConvGemmParams& p);
 int launch_gemm_big(const ConvGemmParams& p, hipStream_t st);
 
+// gemm_rows.hip: dW of the MobileViT-sized token linears under >= 128 k rows, whole rows per workgroup
+struct TnRowsGeom {
+  int n_parts, k_parts;  // workgroup columns over N and K (1 x 1 where the [N x K] block fits one workgroup's accumulators)
+  int NP, KP;            // columns of dY / X per part
+  int WN, WK, PN, PK;    // 16 waves as WN x WK, PN x PK 16 x 16 tiles each
+  int py, px;            // LDS row pitch of the dY / X images in 16-byte chunks
+  int stage_bytes, nstage, ipw;
+  int splits, m_per_split;
+  int dbg;
+};
+bool gemm_tn_rows_plan(int M, int N, int K, TnRowsGeom* out);  // a property of the shape (bf16 pointwise problems)
+bool gemm_tn_rows_eligible(const GemmTNParams& p);
+int launch_gemm_tn_rows(const GemmTNParams& p, hipStream_t st);
+
 // gemm_stream.hip
 bool gemm_stream_eligible(const ConvGemmParams& p);
 int launch_gemm_stream(const ConvGemmParams& p, hipStream_t st);

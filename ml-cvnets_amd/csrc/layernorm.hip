@@ -199,11 +199,28 @@ __global__ __launch_bounds__(256) void ln_fwd_g_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int G>
+// DROP: the kernel also stores dxd = dx * keep-scale — dx as the Dropout in FRONT of this LayerNorm (x = res + Dropout(linear(h)),
+// cvnets/modules/transformer.py:140-155) hands it to that linear's dW / dX GEMMs: the mask is regenerated from (seed, stream id, element
+// index) exactly as cvh_dropout does on the stored dx, so the standalone dropout-backward pass (one read + one write of the token
+// matrix per dropout site) becomes one extra write here
+struct LnDropArgs {
+  void* dxd;
+  const unsigned long long* seed;
+  float p;
+  unsigned int stream_id;
+};
+template <typename T, int G, bool DROP = false>
 __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
                                                        float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C,
-                                                       const T* __restrict__ dres /* optional: dx += dres (residual fork) */) {
+                                                       const T* __restrict__ dres /* optional: dx += dres (residual fork) */,
+                                                       LnDropArgs da = LnDropArgs{nullptr, nullptr, 0.f, 0u}) {
+  DropKey dkey = {0u, 0u};
+  float inv_keep = 1.f;
+  if (DROP) {
+    dkey = drop_key(*da.seed, da.stream_id, da.p);
+    inv_keep = 1.0f / (1.0f - da.p);
+  }
   constexpr int RPW = 64 / G, U = 2;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C], zeroed; every (wave, row group) adds its sums in a fixed order
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -261,6 +278,12 @@ __global__ __launch_bounds__(256) void ln_bwd_g_kernel(const T* __restrict__ x, 
         V8<T> ov;
         v8_pack(o, ov);
         v8_store<T>(dx + row * C + c0, ov);
+        if (DROP) {
+          v8_unpack(ov, o);  // the mask applies to dx as stored
+          dropout_scale8(dkey, (uint64_t)(row * C + c0), inv_keep, o);
+          v8_pack(o, ov);
+          v8_store<T>(reinterpret_cast<T*>(da.dxd) + row * C + c0, ov);
+        }
       }
     }
   }
@@ -326,7 +349,7 @@ extern "C" int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, c
   if (ln_grouped_ok(C) && rows > 0) {  // same partial-row contract: part[g][2][C]
     const int G = ln_group(C);
     const size_t sm = (size_t)2 * C * sizeof(float);
-#define LN_BWD_G(TT, GG) hipLaunchKernelGGL((ln_bwd_g_kernel<TT, GG>), dim3(g), dim3(256), sm, st, (const TT*)x, (const TT*)dy, gamma, mean, rstd, (TT*)dx, part, (size_t)rows, C, (const TT*)dres)
+#define LN_BWD_G(TT, GG) hipLaunchKernelGGL((ln_bwd_g_kernel<TT, GG, false>), dim3(g), dim3(256), sm, st, (const TT*)x, (const TT*)dy, gamma, mean, rstd, (TT*)dx, part, (size_t)rows, C, (const TT*)dres, LnDropArgs{nullptr, nullptr, 0.f, 0u})
     if (dtype == CVH_DT_BF16) { if (G == 16) LN_BWD_G(bf16_t, 16); else if (G == 32) LN_BWD_G(bf16_t, 32); else LN_BWD_G(bf16_t, 64); }
     else if (dtype == CVH_DT_F32) { if (G == 16) LN_BWD_G(float, 16); else if (G == 32) LN_BWD_G(float, 32); else LN_BWD_G(float, 64); }
     else return -1;
@@ -337,6 +360,27 @@ extern "C" int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, c
   if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, (size_t)rows, C, (const bf16_t*)dres);
   else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, (size_t)rows, C, (const float*)dres);
   else return -1;
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+/* cvh_layernorm_bwd_res that also stores dxd = Dropout-backward of dx (mask of (seed, stream_id, p) over the [rows][C] element index, as
+ * cvh_dropout draws it).  cvh_ln_bwd_drop_ok(C) == 0: this width runs on the one-row-per-wave kernels, use cvh_dropout on dx. */
+extern "C" int cvh_ln_bwd_drop_ok(int C) { return (ln_grouped_ok(C) && C % 8 == 0) ? 1 : 0; }
+extern "C" int cvh_layernorm_bwd_res_drop(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                                          void* dx, float* part, long long rows, int C, const void* dres, void* dxd, float drop_p,
+                                          const unsigned long long* seed, unsigned int stream_id, void* stream) {
+  if (!cvh_ln_bwd_drop_ok(C) || rows <= 0 || dxd == nullptr || seed == nullptr || drop_p <= 0.f || drop_p >= 1.f) return -2;
+  const int g = cvh_ln_bwd_rows(rows);
+  hipStream_t st = (hipStream_t)stream;
+  const int G = ln_group(C);
+  const size_t sm = (size_t)2 * C * sizeof(float);
+  const LnDropArgs da{dxd, seed, drop_p, stream_id};
+#define LN_BWD_GD(TT, GG) hipLaunchKernelGGL((ln_bwd_g_kernel<TT, GG, true>), dim3(g), dim3(256), sm, st, (const TT*)x, (const TT*)dy, gamma, mean, rstd, (TT*)dx, part, (size_t)rows, C, (const TT*)dres, da)
+  if (dtype == CVH_DT_BF16) { if (G == 16) LN_BWD_GD(bf16_t, 16); else if (G == 32) LN_BWD_GD(bf16_t, 32); else LN_BWD_GD(bf16_t, 64); }
+  else if (dtype == CVH_DT_F32) { if (G == 16) LN_BWD_GD(float, 16); else if (G == 32) LN_BWD_GD(float, 32); else LN_BWD_GD(float, 64); }
+  else return -1;
+#undef LN_BWD_GD
   CVH_CHECK_LAUNCH();
   return 0;
 }

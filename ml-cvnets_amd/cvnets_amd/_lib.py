@@ -106,6 +106,8 @@ SIGNATURES = {
     "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
     "cvh_layernorm_bwd_res": [I, P, P, P, P, P, P, P, L, I, P, P],
     "cvh_ln_bwd_rows": [L],
+    "cvh_ln_bwd_drop_ok": [I],
+    "cvh_layernorm_bwd_res_drop": [I, P, P, P, P, P, P, P, L, I, P, P, F, P, U, P],
     "cvh_set_tuning": [I, I],
     "cvh_conv_dx_patch": [I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cvh_vit_embed_fwd": [I, P, P, P, P, I, I, I, P],

@@ -1011,6 +1011,50 @@ class BatchNormAct(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # linear on token matrices (+bias +act +dropout +residual)
 # ------------------------------------------------------------------------------------------------
+# Dropout backward without a pass of its own (csrc/layernorm.hip, DROP): x = res + Dropout(linear(h)) is followed by a LayerNorm in every
+# TransformerEncoder; the LayerNorm backward kernel that produces d(x) also stores d(x) * keep-mask, which is what that linear's dW / dX GEMMs
+# consume.  The hand-over: `linear` tags its output with the draw (p, stream id, seed snapshot); the LayerNorm functions remember the tag of
+# their input; their backward leaves the masked gradient in a one-entry slot keyed by the address of the gradient they return, and the
+# linear's backward takes it when address, draw and shape match (anything else — a summed gradient, a hook, another consumer — misses the
+# slot and runs cvh_dropout as before).
+# OFF by default (CVH_LN_DROP=1 switches it on): measured in the 1024-image MobileViT-S step (profiles/r06_ab_runs.txt) the LayerNorm backward
+# kernels grow by 1.18 ms (18 launches, one more write stream each) while the 20 dropout launches they replace cost 0.75 ms — those re-read a
+# tensor the previous kernel has just written, largely out of the 256 MB memory-side cache, so the "saved" read was cheap to begin with.
+_LN_DROP = os.environ.get("CVH_LN_DROP", "0") != "0"
+_dropped_slot = None
+
+
+def _drop_tag_of(x):
+    tag = getattr(x, "_cvh_drop", None) if _LN_DROP else None
+    if tag is None or tag[3] != x._version or tag[4] != x.data_ptr():
+        return None
+    return tag[:3]
+
+
+def _ln_backward_launch(x, dout, gamma, mr, dx, part, rows, C, dres, drop):
+    """cvh_layernorm_bwd_res; with `drop` = (p, stream id, seed) of the Dropout in front of this LayerNorm also the masked copy of dx"""
+    global _dropped_slot
+    if drop is not None and _lib.query("cvh_ln_bwd_drop_ok", C):
+        p, sid, seed = drop
+        dxd = torch.empty_like(dx)
+        _lib.call("cvh_layernorm_bwd_res_drop", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _p(dres),
+                  _p(dxd), float(p), _p(seed), int(sid), _stream())
+        _dropped_slot = (dx.data_ptr(), tuple(dx.shape), dx.dtype, float(p), int(sid), seed.data_ptr(), dxd)
+        return
+    _lib.call("cvh_layernorm_bwd_res", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _p(dres), _stream())
+
+
+def _take_dropped(dout, p, sid, seed):
+    global _dropped_slot
+    slot, _dropped_slot = _dropped_slot, None
+    if slot is None or seed is None:
+        return None
+    ptr, shape, dtype, sp, ssid, sseed, dxd = slot
+    if ptr == dout.data_ptr() and shape == tuple(dout.shape) and dtype == dout.dtype and sp == float(p) and ssid == int(sid) and sseed == seed.data_ptr():
+        return dxd
+    return None
+
+
 class LinearAct(torch.autograd.Function):
     """LinearLayer.forward = F.linear (cvnets/layers/linear_layer.py:74-91) with the activation / Dropout / residual
     add that follow it in TransformerEncoder (cvnets/modules/transformer.py:140-155) fused into the GEMM epilogue.
@@ -1061,8 +1105,10 @@ class LinearAct(torch.autograd.Function):
             dout = dout.contiguous()
             dy = dout
             if drop_p > 0:
-                dy = torch.empty_like(dout)
-                _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(ctx.seed), stream_id, _stream())
+                dy = _take_dropped(dout, drop_p, stream_id, ctx.seed)  # formed by the LayerNorm backward that produced dout
+                if dy is None:
+                    dy = torch.empty_like(dout)
+                    _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(ctx.seed), stream_id, _stream())
             if act != ACT_NONE:
                 dy = _act_backward(pre, dy, act, rows, N)
             if expose_pre and dpre is not None:
@@ -1093,7 +1139,10 @@ class LinearAct(torch.autograd.Function):
 def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None, expose_pre=False, in_pre=None, in_act=ACT_NONE):
     sid = next_stream_id() if drop_p > 0 else 0
     _trace_site("linear", sid, drop_p, (x2d.shape[0], weight.shape[0]))
-    return LinearAct.apply(x2d, weight, bias, residual, in_pre, (int(act), float(drop_p), sid, bool(expose_pre), int(in_act)))
+    res = LinearAct.apply(x2d, weight, bias, residual, in_pre, (int(act), float(drop_p), sid, bool(expose_pre), int(in_act)))
+    if drop_p > 0 and _LN_DROP and isinstance(res, torch.Tensor):
+        res._cvh_drop = (float(drop_p), sid, dropout_seed(x2d.device), res._version, res.data_ptr())
+    return res
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1145,8 +1194,9 @@ def layer_norm_tokens(x2d, ln, seqmap):
 # ------------------------------------------------------------------------------------------------
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, drop=None):
         _check_dev(x)
+        ctx.drop = drop
         rows, C = x.shape
         y = torch.empty_like(x)
         mr = _f32(2, x.device, rows)
@@ -1163,20 +1213,20 @@ class LayerNormFn(torch.autograd.Function):
         R = _lib.query("cvh_ln_bwd_rows", rows)
         part = _f32(R * 2 * C, x.device)
         dx = torch.empty_like(x)
-        _lib.call("cvh_layernorm_bwd", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _stream())
+        _ln_backward_launch(x, dout, gamma, mr, dx, part, rows, C, None, ctx.drop)
         sg, sb = _grad_sink(gamma), _grad_sink(ctx.beta)
         if sg is not None and sb is not None:
             if not (defer_reduce(part, sg, R, 2 * C, C) and defer_reduce(part, sb, R, 2 * C, C, part_offset=C)):
                 _lib.call("cvh_sum_partials", _p(part), R, 2 * C, C, _p(sg), 1.0, 1, _stream())
                 _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, R, 2 * C, C, _p(sb), 1.0, 1, _stream())
-            return dx, None, None, None
+            return dx, None, None, None, None
         dgb = _f32(2 * C, x.device)
         _lib.call("cvh_sum_partials", _p(part), R, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())
-        return dx, dgb[:C], dgb[C:], None
+        return dx, dgb[:C], dgb[C:], None, None
 
 
 def layer_norm(x2d, gamma, beta, eps=1e-5):
-    return LayerNormFn.apply(x2d, gamma, beta, float(eps))
+    return LayerNormFn.apply(x2d, gamma, beta, float(eps), _drop_tag_of(x2d))
 
 
 _LN_FORK = os.environ.get("CVH_LN_FORK", "1") != "0"
@@ -1189,13 +1239,14 @@ class LayerNormForkFn(torch.autograd.Function):
     inside the LayerNorm backward kernel (cvh_layernorm_bwd_res)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, drop=None):
         _check_dev(x)
         rows, C = x.shape
         y = torch.empty_like(x)
         mr = _f32(2, x.device, rows)
         _lib.call("cvh_layernorm_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mr[0]), _p(mr[1]), rows, C, float(eps), _stream())
         ctx.beta = beta
+        ctx.drop = drop
         ctx.save_for_backward(x, gamma, mr)
         return x.view_as(x), y
 
@@ -1204,7 +1255,7 @@ class LayerNormForkFn(torch.autograd.Function):
         x, gamma, mr = ctx.saved_tensors
         rows, C = x.shape
         if dout is None:  # only the pass-through was used
-            return dres, None, None, None
+            return dres, None, None, None, None
         dout = dout.contiguous()
         if dres is not None:
             dres = dres.contiguous()
@@ -1213,16 +1264,16 @@ class LayerNormForkFn(torch.autograd.Function):
         R = _lib.query("cvh_ln_bwd_rows", rows)
         part = _f32(R * 2 * C, x.device)
         dx = torch.empty_like(x)
-        _lib.call("cvh_layernorm_bwd_res", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, _p(dres), _stream())
+        _ln_backward_launch(x, dout, gamma, mr, dx, part, rows, C, dres, ctx.drop)
         sg, sb = _grad_sink(gamma), _grad_sink(ctx.beta)
         if sg is not None and sb is not None:
             if not (defer_reduce(part, sg, R, 2 * C, C) and defer_reduce(part, sb, R, 2 * C, C, part_offset=C)):
                 _lib.call("cvh_sum_partials", _p(part), R, 2 * C, C, _p(sg), 1.0, 1, _stream())
                 _lib.call("cvh_sum_partials", part.data_ptr() + 4 * C, R, 2 * C, C, _p(sb), 1.0, 1, _stream())
-            return dx, None, None, None
+            return dx, None, None, None, None
         dgb = _f32(2 * C, x.device)
         _lib.call("cvh_sum_partials", _p(part), R, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())
-        return dx, dgb[:C], dgb[C:], None
+        return dx, dgb[:C], dgb[C:], None, None
 
 
 def layer_norm_fork(x2d, ln, seqmap):
@@ -1230,7 +1281,7 @@ def layer_norm_fork(x2d, ln, seqmap):
     S, C = seqmap[1], x2d.shape[1]
     if (S == C and getattr(ln, "reference_quirk", True)) or not torch.is_grad_enabled() or not x2d.requires_grad or not _LN_FORK:
         return x2d, layer_norm_tokens(x2d, ln, seqmap)
-    return LayerNormForkFn.apply(x2d, ln.weight, ln.bias, float(ln.eps))
+    return LayerNormForkFn.apply(x2d, ln.weight, ln.bias, float(ln.eps), _drop_tag_of(x2d))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -164,6 +164,7 @@ def counters(reset: bool = False):
 # ---- the process-wide default communicator (what ddp.DistributedDataParallel and gather_all_features use) ---------------------------------
 _default: Optional[Communicator] = None
 _generation = 0
+_attempted = False  # init_default has made its (collective) decision for this process
 
 
 def default() -> Optional[Communicator]:
@@ -175,15 +176,20 @@ def init_default(device=None, store=None, world: Optional[int] = None, rank: Opt
     default group (the launcher's env:// TCP store), else — a world of one — none at all.  Returns None (and leaves the callers on
     torch.distributed) when the device is not a GPU, librccl is missing, CVH_OWN_COMM=0, or bring-up / self-test fails: the failure is
     reported once on stderr, never silently."""
-    global _default, _generation
+    global _default, _generation, _attempted
     if _default is not None:
         return _default
-    if os.environ.get("CVH_OWN_COMM", "1") == "0":
+    if _attempted:  # the fall-back decision is made ONCE per process: a failed bring-up is not retried by every DDP constructor / CLIP gather
         return None
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if dev.type != "cuda" or not torch.cuda.is_available() or not available():
-        return None
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        return None  # (a CPU process group has no use for it: every rank of such a job returns here alike)
+    _attempted = True
     import torch.distributed as dist
+
+    # CVH_OWN_COMM=0 / a missing librccl are LOCAL facts: they enter the collective vote below as "could not bring it up" instead of returning
+    # before it (a rank that left early would leave the others blocked in the store exchange and the MIN all-reduce)
+    local_ok = os.environ.get("CVH_OWN_COMM", "1") != "0" and available()
 
     if world is None or rank is None:
         if dist.is_available() and dist.is_initialized():
@@ -194,6 +200,8 @@ def init_default(device=None, store=None, world: Optional[int] = None, rank: Opt
 
     c = None
     try:
+        if not local_ok:
+            raise RuntimeError("switched off (CVH_OWN_COMM=0)" if os.environ.get("CVH_OWN_COMM", "1") == "0" else "librccl not found")
         if world == 1:
             c = Communicator.single(dev)
         else:
@@ -225,7 +233,8 @@ def init_default(device=None, store=None, world: Optional[int] = None, rank: Opt
 
 
 def destroy_default() -> None:
-    global _default
+    global _default, _attempted
+    _attempted = False  # a later init_default may try again (tests; a re-initialised process group)
     if _default is not None:
         _default.destroy()
         _default = None

@@ -34,6 +34,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -156,11 +157,22 @@ class _Bucket:
                 p.grad = v
 
 
+_LIVE = weakref.WeakSet()  # the wrappers of this process (cvnets_amd.optim asks them before it updates parameters)
+
+
+def exchange_pending() -> None:
+    """called by the optimizer step: every wrapper whose last hooked forward has not been followed by a gradient exchange runs it now"""
+    for d in list(_LIVE):
+        d.assert_exchanged()
+
+
 class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, bucket_cap_mb: float = 8.0, overlap: bool = True, broadcast_buffers: bool = True,
                  process_group=None, force_collectives: Optional[bool] = None, first_bucket_mb: float = 1.0,
                  boundary_overlap: bool = False):
         super().__init__()
+        _LIVE.add(self)
+        self._expect_exchange = False
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
@@ -324,14 +336,18 @@ class DistributedDataParallel(nn.Module):
     def _boundary(self, ci: int, fid: int):
         """backward has produced the gradient w.r.t. the input of candidate `ci`: every parameter of the candidates that ran at or after it has
         its gradient kernels (or deferred partial sums) enqueued"""
-        if not (self.active and self.boundary_overlap and self.boundary_enabled) or self._in_no_sync or not self._fwd_ok.get(fid, False):
+        if not (self.active and self.boundary_overlap and self.boundary_enabled) or self._in_no_sync:
             return None  # (no_sync: the micro-steps of a gradient accumulation exchange nothing — torch DDP's contract)
+        # the end-of-backward exchange is queued by WHICHEVER hook of this backward fires first — also on the steps on which the boundary
+        # order is still being learned (`_fwd_ok` false): with in-place parameter gradients no post-accumulate hook exists to do it
         tid = torch._C._current_graph_task_id()
-        if self._callback_task != tid:
+        if tid >= 0 and self._callback_task != tid:
             if self._callback_task is not None:
                 self._discard_stale_task()
             self._callback_task = tid
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        if not self._fwd_ok.get(fid, False):
+            return None
         from . import ops
         ops.flush_deferred_reductions()  # the partial sums queued so far all belong to candidates that ran at or after this one
         for b in self._boundary_buckets.get(ci, ()):
@@ -436,6 +452,22 @@ class DistributedDataParallel(nn.Module):
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         self._average()
         self._callback_task = None
+        self._expect_exchange = False
+
+    def assert_exchanged(self):
+        """Safety net of the in-place-gradient mode, called by cvnets_amd.optim.AdamW.step (exchange_pending below): a forward whose outputs
+        were hooked must have been followed by a gradient exchange before the parameters are updated.  If the optimizer steps and no hook
+        of that forward's backward has fired, the ranks would diverge silently: exchange now (correct, not overlapped) and say so once.
+        (A forward that was never differentiated ends up here too: an extra all-reduce of unchanged buckets, harmless.)"""
+        if not (self.active and getattr(self, "_expect_exchange", False)) or self._in_no_sync:
+            return
+        import warnings
+        if not getattr(self, "_warned_late_exchange", False):
+            self._warned_late_exchange = True
+            warnings.warn("cvnets_amd.ddp: the optimizer steps although no gradient exchange has run since the last hooked forward (no hook on "
+                          "the wrapped model's outputs fired during backward); exchanging the gradients now, without overlap")
+        self.allreduce_flat()
+        self._expect_exchange = False
 
     def overlap_report(self) -> dict:
         """how the gradient exchange has been scheduled so far: buckets, their sizes, launches before / at the end of backward"""
@@ -527,9 +559,14 @@ class DistributedDataParallel(nn.Module):
             if ops._INPLACE_PARAM_GRADS:
                 # in-place parameter gradients never reach autograd, so no post-accumulate hook will queue `finish`: a hook on the output
                 # does it when backward starts (buckets not started by a boundary are then exchanged at the end of backward)
-                t = _first_tensor(out)
-                if t is not None and t.requires_grad:
-                    t.register_hook(self._backward_started)
+                # EVERY output that requires grad gets the hook (a dict / tuple output whose first tensor is off the loss path — an augmented
+                # input, an auxiliary head — must not decide whether the ranks exchange gradients); `_backward_started` is idempotent per backward
+                hooked = 0
+                for t in _tensors_of(out):
+                    if t.requires_grad:
+                        t.register_hook(self._backward_started)
+                        hooked += 1
+                self._expect_exchange = hooked > 0
         return out
 
     def _backward_started(self, grad):
@@ -542,16 +579,21 @@ class DistributedDataParallel(nn.Module):
         return None
 
 
-def _first_tensor(out):
+def _tensors_of(out):
+    """every tensor of a (nested) tensor / dict / list / tuple output"""
     if isinstance(out, torch.Tensor):
-        return out
-    if isinstance(out, dict):
-        out = list(out.values())
-    if isinstance(out, (list, tuple)):
+        yield out
+    elif isinstance(out, dict):
+        for o in out.values():
+            yield from _tensors_of(o)
+    elif isinstance(out, (list, tuple)):
         for o in out:
-            t = _first_tensor(o)
-            if t is not None:
-                return t
+            yield from _tensors_of(o)
+
+
+def _first_tensor(out):
+    for t in _tensors_of(out):
+        return t
     return None
 
 

@@ -202,6 +202,10 @@ class AdamW(torch.optim.Optimizer):
     def step(self, closure=None, inv_grad_scale: Optional[torch.Tensor] = None, sync_hyperparameters: bool = True):
         loss = closure() if closure is not None else None
         ops.finish_backward()  # side-stream dW work / deferred reductions of a backward whose end-of-backward callback was lost
+        import sys
+        _ddp = sys.modules.get(__package__ + ".ddp")
+        if _ddp is not None:
+            _ddp.exchange_pending()  # a hooked forward whose backward never reached the gradient exchange: run it before the update
         if not any(p.grad is not None for g in self.param_groups for p in g["params"]):
             return loss  # torch.optim.AdamW.step() with no gradients anywhere is a no-op
         plan = self._plan

@@ -373,8 +373,8 @@ class _OutOfOrderNet(torch.nn.Module):
 
 def test_boundary_overlap_learns_the_execution_order():
     """ddp.py round 5: the boundary candidates' EXECUTION order is learnt (first guess: registration order).  A model whose children run in
-    another order (ViT: `pos_embed` is registered after the blocks it precedes) exchanges at the end of backward on its first step and
-    overlaps from the second one on, with the blocks of a Sequential container as boundaries of their own; gradients equal the plain
+    another order (ViT: `pos_embed` is registered after the blocks it precedes) exchanges at the end of backward on its first step (the end-of-backward callback is queued by the first boundary hook that
+    fires, whether or not its order is trusted yet) and overlaps from the second one on, with the blocks of a Sequential container as boundaries of their own; gradients equal the plain
     backward's in both steps; a checkpoint-style forward inside backward does not disturb the learnt order."""
     sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
     from cvnets_amd.ddp import DistributedDataParallel
@@ -397,13 +397,12 @@ def test_boundary_overlap_learns_the_execution_order():
             ddp.zero_grad()
             e0, l0, f0 = ddp.early_launches, ddp.late_launches, ddp.finish_count
             ddp(x).square().mean().backward()
-            if ddp.finish_count == f0:     # no boundary fired (the first step, on the wrong guess): exchange explicitly, as bench.py does
-                ddp.allreduce_flat()
+            assert ddp.finish_count == f0 + 1  # also on the first step (wrong guess, no boundary launches anything): the first boundary hook of a backward queues the end-of-backward exchange
             steps.append((ddp.early_launches - e0, ddp.late_launches - l0))
             for p, w in zip(net.parameters(), want):
                 assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7)
         assert ddp._order == (0, 6, 2, 3, 4, 1, 5) and ddp._order != reg_order          # a, pos, blocks.0-2, norm, head
-        assert steps[0] == (0, 0) and steps[1][0] >= 3 and steps[2] == steps[1], steps   # first step (wrong guess): no boundary; then overlapped
+        assert steps[0] == (0, len(ddp.buckets)) and steps[1][0] >= 3 and steps[2] == steps[1], steps   # first step (wrong guess): everything at the end of backward; then overlapped
         assert all(e + l == len(ddp.buckets) for e, l in steps[1:]), (steps, len(ddp.buckets))
         # the bucket of the root-level parameter never belongs to a boundary
         assert all(ddp._bucket_of[net.cls_token] not in lst for lst in ddp._boundary_buckets.values())
@@ -466,3 +465,47 @@ def test_own_communicator_fallback_is_a_collective_decision(fail_rank):
         assert got[0] == [True, True, True] and got[1][0] and got[1][2], got    # both None; rank 0's communicator was destroyed
     else:
         assert got[0] == [False, False, False] and got[1] == [False, False, False], got
+
+
+def test_inplace_gradient_mode_hooks_every_output_and_the_optimizer_safety_net(monkeypatch):
+    """with in-place parameter gradients no post-accumulate hook exists; the exchange is queued by a hook on the model
+    OUTPUT.  A dict output whose first tensor is off the loss path (an augmented input next to the logits) must not leave the backward without
+    its exchange: every output that requires grad carries the hook.  And if no hook fires at all, the optimizer step runs the exchange itself
+    (cvnets_amd.ddp.exchange_pending) instead of letting the ranks diverge."""
+    sys.path.insert(0, os.path.join(REPO, "ml-cvnets_amd"))
+    import warnings
+    from cvnets_amd import ddp as ddp_mod
+    from cvnets_amd import ops
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", init_method="env://")
+    try:
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.fc = torch.nn.Linear(8, 4)
+
+            def forward(self, x):
+                return {"augmented_tensor": x, "logits": self.fc(x), "aux": [self.fc(x) * 2.0]}
+
+        monkeypatch.setattr(ops, "_INPLACE_PARAM_GRADS", True)
+        d = ddp_mod.DistributedDataParallel(Net(), force_collectives=True)
+        x = torch.randn(3, 8)  # requires no gradient: the FIRST tensor of the output is off the loss path
+        f0 = d.finish_count
+        out = d(x)
+        assert d._expect_exchange
+        out["logits"].square().mean().backward()
+        assert d.finish_count == f0 + 1 and not d._expect_exchange
+        # both hooked outputs on the loss path: still one exchange per backward
+        out = d(x)
+        (out["logits"].sum() + out["aux"][0].sum()).backward()
+        assert d.finish_count == f0 + 2
+        # no hook fires (the loss does not depend on the wrapped model's outputs): the optimizer step exchanges
+        d(x)
+        assert d._expect_exchange
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ddp_mod.exchange_pending()
+        assert not d._expect_exchange and any("without overlap" in str(m.message) for m in w)
+    finally:
+        dist.destroy_process_group()

@@ -468,11 +468,11 @@ def text_transformer_forward(sd: Dict[str, Tensor], prefix: str, tokens: Tensor,
     x = emb + pe.reshape(1, s, -1).to(emb.dtype)
     mask = None
     if causal:
-        mask = torch.full((s, s), float("-inf")).triu_(1).unsqueeze(0).expand(tokens.shape[0], -1, -1)
+        mask = torch.full((s, s), float("-inf"), device=tokens.device).triu_(1).unsqueeze(0).expand(tokens.shape[0], -1, -1)
     for i in range(n_layers):
         x = transformer_encoder(sd, f"{prefix}transformer.{i}", x, heads, act="gelu", attn_mask=mask)
     x = F.layer_norm(x, (x.shape[-1],), sd[prefix + "final_layer_norm.weight"], sd[prefix + "final_layer_norm.bias"], 1e-5)
-    x = x[torch.arange(tokens.shape[0]), tokens.argmax(dim=-1)]
+    x = x[torch.arange(tokens.shape[0], device=tokens.device), tokens.argmax(dim=-1)]
     return F.normalize(x @ sd[prefix + "projection_layer"], dim=-1)
 
 
@@ -492,7 +492,7 @@ def contrastive_loss_clip(img: Tensor, txt: Tensor, logit_scale: Tensor, all_img
     logits_per_image = logit_scale * (img @ all_txt.transpose(0, 1))
     logits_per_text = logit_scale * (txt @ all_img.transpose(0, 1))
     n = logits_per_image.shape[0]
-    labels = torch.arange(n, dtype=torch.long) + n * rank
+    labels = torch.arange(n, dtype=torch.long, device=img.device) + n * rank
     text_loss = F.cross_entropy(logits_per_text, labels) * 0.5
     image_loss = F.cross_entropy(logits_per_image, labels) * 0.5
     return image_loss + text_loss, image_loss, text_loss

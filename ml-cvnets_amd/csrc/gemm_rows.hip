@@ -69,7 +69,6 @@ __global__ __launch_bounds__(64 * GR_WAVES) void gemm_tn_rows_kernel(GemmTNParam
 
   // ---- this lane's direct-to-LDS pieces: block b = wave + 16 j of the stage image covers chunk slots 64 b ... 64 b + 63 ----
   const int ychunks = GR_ROWS * g.py, stage_chunks = ychunks + GR_ROWS * g.px, nblk = stage_chunks / 64;
-  (void)nblk;  // blocks past the image (the last round of the deal) read the zero line into the stage's padding
   const bf16_t* src[IPW];
   int srow[IPW], sinc[IPW];
 #pragma unroll
@@ -90,7 +89,9 @@ __global__ __launch_bounds__(64 * GR_WAVES) void gemm_tn_rows_kernel(GemmTNParam
     for (int j = 0; j < IPW; ++j) {
       if (!(g.dbg & 4)) {
         const bool ok = row0 + srow[j] + st * rstep < p.M;
-        gr_glds16(ok ? reinterpret_cast<const void*>(src[j] + (size_t)st * rstep * sinc[j]) : reinterpret_cast<const void*>(gr_zero_line), dst + j * (GR_WAVES * 1024));
+        // a block past the stage image (the last round of the deal) lands in a scratch area behind the stages: every wave issues IPW instructions
+        unsigned char* d = (wave + GR_WAVES * j < nblk) ? dst + j * (GR_WAVES * 1024) : smem + GR_NSTAGE * g.stage_bytes + wave * 1024;
+        gr_glds16(ok ? reinterpret_cast<const void*>(src[j] + (size_t)st * rstep * sinc[j]) : reinterpret_cast<const void*>(gr_zero_line), d);
       }
     }
   };
@@ -135,26 +136,28 @@ __global__ __launch_bounds__(64 * GR_WAVES) void gemm_tn_rows_kernel(GemmTNParam
 #pragma unroll
       for (int j = 0; j < 8; ++j) cs[j] += f[j];
     }
-    bf16x8_t af[PN], bf[PK];
+    bf16x8_t bf[PK];
     if (!(g.dbg & 1)) {
+#pragma unroll
+      for (int j = 0; j < PK; ++j) {
+        const int kb = wk * PK + j;
+        bf[j] = gr_tr_frag(img + b_off + (kb < tkb ? kb : 0) * 32, b_hi);
+      }
+    }
+    // one dY fragment at a time (wide tile rectangles: PN + PK fragments next to PN * PK accumulators do not fit 128 registers; the
+    // scheduling barrier keeps the compiler from hoisting every fragment read to the top)
 #pragma unroll
     for (int i = 0; i < PN; ++i) {
       const int nb = wn * PN + i;
-      af[i] = gr_tr_frag(img + a_off + (nb < tnb ? nb : 0) * 32, a_hi);
-    }
-#pragma unroll
-    for (int j = 0; j < PK; ++j) {
-      const int kb = wk * PK + j;
-      bf[j] = gr_tr_frag(img + b_off + (kb < tkb ? kb : 0) * 32, b_hi);
-    }
-    }
-#pragma unroll
-    for (int i = 0; i < PN; ++i)
+      bf16x8_t af;
+      if (!(g.dbg & 1)) af = gr_tr_frag(img + a_off + (nb < tnb ? nb : 0) * 32, a_hi);
 #pragma unroll
       for (int j = 0; j < PK; ++j) {
-        if (!(g.dbg & 2) && wn * PN + i < tnb && wk * PK + j < tkb)  // wave-uniform
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);  // D[n][k] += sum_m dY[m][n] X[m][k]
+        if (!(g.dbg & 2) && nb < tnb && wk * PK + j < tkb)  // wave-uniform
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);  // D[n][k] += sum_m dY[m][n] X[m][k]
       }
+      if (PN * PK > 16 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- partial results ----
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(64 * GR_WAVES) void gemm_tn_rows_kernel(GemmTNParam
 
 // instantiations: per-wave tile rectangles (PN x PK); a plan's rectangle is rounded up to the next one
 struct GrInst { int pn, pk; };
-constexpr GrInst GR_INST[] = {{3, 3}, {4, 4}, {5, 3}, {3, 5}};
+constexpr GrInst GR_INST[] = {{3, 3}, {4, 4}, {5, 3}, {3, 5}};  // (a 7 x 3 rectangle — N = 432 in one part — spills 21 registers and measured 505 us against the tiled kernel's 399)
 constexpr int GR_MAXI = 3;
 
 int pad_pitch(int chunks) {  // = 2 (mod 4): 8 consecutive rows x 8 dwords of a transpose read fall on 8 disjoint bank octets
@@ -224,8 +227,8 @@ bool gemm_tn_rows_plan(int M, int N, int K, TnRowsGeom* out) {
         const int nblk = stage_chunks / 64;  // (py + px) % 4 == 0: whole 1 KB blocks
         g.ipw = (nblk + GR_WAVES - 1) / GR_WAVES;
         if (g.ipw > GR_MAXI) continue;
-        g.stage_bytes = g.ipw * GR_WAVES * 1024;  // the blocks of a stage are dealt to the waves round-robin
-        if (GR_NSTAGE * g.stage_bytes > 160 * 1024) continue;
+        g.stage_bytes = nblk * 1024;  // the blocks of a stage are dealt to the waves round-robin; the surplus of the last round goes to a scratch area
+        if (GR_NSTAGE * g.stage_bytes + ((nblk % GR_WAVES) ? GR_WAVES * 1024 : 0) > 160 * 1024) continue;
         g.nstage = GR_NSTAGE;
         g.dbg = cvh_tune_get(24);
         const int ns = GR_NSTAGE;
@@ -259,7 +262,7 @@ int launch_gemm_tn_rows(const GemmTNParams& p, hipStream_t st) {
   TnRowsGeom g;
   if (!gemm_tn_rows_plan(p.M, p.N, p.Ktot, &g)) return -2;
   if (g.m_per_split != p.m_per_split) return -2;  // tn_plan and this launch must agree on the partial rows
-  const size_t smem = (size_t)g.nstage * g.stage_bytes;
+  const size_t smem = (size_t)g.nstage * g.stage_bytes + (((g.stage_bytes / 1024) % GR_WAVES) ? GR_WAVES * 1024 : 0);
   const dim3 grid(g.splits * g.n_parts * g.k_parts), block(64 * GR_WAVES);
 #define GR_LAUNCH(PN_, PK_, I_)                                                                                               \
   if (g.PN == PN_ && g.PK == PK_ && g.ipw == I_) {                                                                            \

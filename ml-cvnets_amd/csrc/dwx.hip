@@ -435,6 +435,12 @@ struct DwxBwdParams {
   int tiles_h, tiles_w, ntiles, chunks;
 };
 
+#ifndef DXB_DBG
+#define DXB_DBG 0  // developer builds (tools/build_variant.py ... -DDXB_DBG=bits): skip pieces of dwx_bwd_kernel to time them; results are WRONG when non-zero.
+#endif             // 1 no g1 stores, 2 no tile loads after the first, 4 no exp / rcp (SiLU, SiLU'), 8 no depthwise dW product, 16 no stencil MFMAs, 32 no expansion MFMAs
+#ifndef DXB_WAIT
+#define DXB_WAIT 1
+#endif
 template <int S, int CIN>
 __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
   using TL = DxTile<S>;
@@ -603,8 +609,11 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
         }
       }
     }
+#if DXB_WAIT == 1
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), stated where every path passes
+#endif
     __syncthreads();
-    if (tix + t_step < p.ntiles) load_tile(tix + t_step);  // next tile's operands, in flight under this tile's arithmetic
+    if (tix + t_step < p.ntiles && !(DXB_DBG & 2)) load_tile(tix + t_step);  // next tile's operands, in flight under this tile's arithmetic
 
     // ---- per 16-pixel block: y1 -> z, act', xhat;  dz = stencil^T(dy);  g1 = dz * act' ----
     // Unrolled by four: two waves per SIMD leave the scheduler little else to overlap a block's MFMAs and LDS reads with the previous block's
@@ -630,10 +639,12 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
       f32x4_t a1 = {0.f, 0.f, 0.f, 0.f};
       const bf16_t* xrow = xo + opx * XP + 8 * l4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) a1 = mfma16(w1f[ks], *reinterpret_cast<const bf16x8_t*>(xrow + 32 * ks), a1);
+      for (int ks = 0; ks < KS; ++ks)
+        if (!(DXB_DBG & 32)) a1 = mfma16(w1f[ks], *reinterpret_cast<const bf16x8_t*>(xrow + 32 * ks), a1);
 
       f32x4_t a2 = {0.f, 0.f, 0.f, 0.f};
-      if (S == 1) {
+      if (DXB_DBG & 16) {
+      } else if (S == 1) {
 #pragma unroll
         for (int tp = 0; tp < 5; ++tp) {
           int t = 2 * tp + slot;
@@ -673,9 +684,9 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
         const f32x2_t y = {a1[2 * h], a1[2 * h + 1]};
         const f32x2_t yh = cs * y + csh;
         const f32x2_t t = cn * y + cnh;
-        f32x2_t d = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        f32x2_t d = (DXB_DBG & 4) ? t : f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
         d = d + 1.0f;
-        const f32x2_t sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2_t sg = (DXB_DBG & 4) ? d : f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
         const f32x2_t z = yh * sg;
         const f32x2_t gp = sg * (yh * (1.0f - sg) + 1.0f);
         const f32x2_t g = f32x2_t{a2[2 * h], a2[2 * h + 1]} * gp;
@@ -688,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
       *reinterpret_cast<uint2*>(zt + opx * DX_AP + 16 * wave + 4 * l4) = make_uint2(zw[0] & zm, zw[1] & zm);
       const int goff = (int)(__umul24(__umul24(r, p.W) + c, hid)) + cw + 4 * l4;  // elements from the tile's first pixel
       if (fast) {  // wave-uniform fast path: no per-lane bounds test
-        *reinterpret_cast<uint2*>(gbase + goff) = make_uint2(gw[0], gw[1]);
+        if (!(DXB_DBG & 1)) *reinterpret_cast<uint2*>(gbase + goff) = make_uint2(gw[0], gw[1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           s1[h] += gq[h];
@@ -706,7 +717,8 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
     wave_lds_sync();
 
     // ---- depthwise weight gradient: diagonal of dy_shifted^T z, contraction over the tile's own pixels ----
-    if (S == 1) {
+    if (DXB_DBG & 8) {
+    } else if (S == 1) {
       // K step ks = tile rows 2 ks, 2 ks + 1; K slot (l4, j) <-> pixel (row 2 ks + (j >> 2), column 4 l4 + (j & 3))
 #pragma unroll 1
       for (int ks = 0; ks < 4; ++ks) {

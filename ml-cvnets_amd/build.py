@@ -19,7 +19,7 @@ INC = os.path.join(os.path.dirname(HERE), "include")
 BUILD = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcvnets_hip.so")
-SOURCES = ["gemm.hip", "gemm_fx.hip", "gemm_big.hip", "gemm_stream.hip", "gemm_rows.hip", "conv3x3.hip", "conv3x3_dw.hip", "stem.hip", "ir_bwd.hip", "ir_fwd.hip", "elementwise.hip", "dwconv.hip", "dwfused.hip", "dwx.hip", "dwxs.hip", "bngram.hip", "ir_pb.hip", "bnlink.hip", "layernorm.hip", "attention.hip", "attn_res.hip", "tokens.hip", "linattn.hip", "optim.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "gemm_fx.hip", "gemm_big.hip", "gemm_stream.hip", "gemm_rows.hip", "conv3x3.hip", "conv3x3_dw.hip", "stem.hip", "ir_bwd.hip", "ir_fwd.hip", "elementwise.hip", "dwconv.hip", "dwfused.hip", "dwx.hip", "dwxs.hip", "bngram.hip", "ir_pb.hip", "bnlink.hip", "layernorm.hip", "attention.hip", "tokens.hip", "linattn.hip", "optim.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + CSRC, "-I" + INC]
 # hardware float atomics (instead of compare-and-swap loops) only where a kernel issues a float atomicAdd at all — none of them runs in the
 # MobileViT / ViT training step (reproducibility): the token-embedding gradient of CLIP (tokens.hip), the token-axis

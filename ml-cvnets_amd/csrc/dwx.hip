@@ -438,9 +438,6 @@ struct DwxBwdParams {
 #ifndef DXB_DBG
 #define DXB_DBG 0  // developer builds (tools/build_variant.py ... -DDXB_DBG=bits): skip pieces of dwx_bwd_kernel to time them; results are WRONG when non-zero.
 #endif             // 1 no g1 stores, 2 no tile loads after the first, 4 no exp / rcp (SiLU, SiLU'), 8 no depthwise dW product, 16 no stencil MFMAs, 32 no expansion MFMAs
-#ifndef DXB_WAIT
-#define DXB_WAIT 1
-#endif
 template <int S, int CIN>
 __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
   using TL = DxTile<S>;
@@ -609,9 +606,6 @@ __global__ __launch_bounds__(256, 2) void dwx_bwd_kernel(DwxBwdParams p) {
         }
       }
     }
-#if DXB_WAIT == 1
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), stated where every path passes
-#endif
     __syncthreads();
     if (tix + t_step < p.ntiles && !(DXB_DBG & 2)) load_tile(tix + t_step);  // next tile's operands, in flight under this tile's arithmetic
 

@@ -402,6 +402,13 @@ int cvh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
                       long long rows, int C, float eps, void* stream);
 int cvh_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
                       float* part, long long rows, int C, void* stream);
+/* Channel-FIRST branch of the same class on a feature map (layer_norm.py:53-66: x.shape[1] == C, x.ndim > 2): per pixel, over its channels,
+ * y = beta[c] + gamma[c] * (x - u) / (std + eps) with the biased std - on the NHWC storage a row-wise normalisation of [rows = pixels][C].
+ * rstd[] = 1 / (std + eps); part = cvh_ln_bwd_rows(rows) partial rows [2][C] of dgamma / dbeta. */
+int cvh_layernorm_cf_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         long long rows, int C, float eps, void* stream);
+int cvh_layernorm_cf_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                         float* part, long long rows, int C, float eps, void* stream);
 /* the same with dx += dres: the gradient arriving over the residual branch that forks off in front of the LayerNorm (x -> LN(x) and
  * x -> ... + x, cvnets/modules/transformer.py:139-155) joins inside this kernel instead of in a separate elementwise add */
 int cvh_layernorm_bwd_res(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,

@@ -6,7 +6,8 @@
 
 #define LN_MAXIT 4  // 64 lanes * 4 elements * 4 iterations = 1024 channels
 
-template <typename T>
+// CF: the reference's channel-first formula (x - u) / (std + eps) (layer_norm.py:53-66) instead of (x - u) / sqrt(var + eps)
+template <typename T, bool CF = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, size_t rows, int C,
                                                      float eps) {
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       }
     }
     const float var = wave_sum(q) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    const float rstd = CF ? 1.0f / (sqrtf(var) + eps) : 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int it = 0; it < LN_MAXIT; ++it) {
       const int ch = lane + it * 64;
@@ -58,10 +59,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; partials of dgamma = sum dy*xhat, dbeta = sum dy
+// cf_eps > 0: the row statistic is r = 1 / (std + eps) (channel-first formula): d r / d var = -r^2 / (2 std) instead of -r^3 / 2, i.e. the
+// xhat term is divided by std * r = 1 - eps * r
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C, const T* __restrict__ dres) {
+                                                     float* __restrict__ part /*[grid][2][C]*/, size_t rows, int C, const T* __restrict__ dres,
+                                                     float cf_eps = 0.f) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C / 4;
@@ -97,7 +101,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
         for (int e = 0; e < 4; ++e) { xh[it][e] = 0.f; g[it][e] = 0.f; }
       }
     }
-    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+    const float m1 = wave_sum(s1) / (float)C;
+    float m2 = wave_sum(s2) / (float)C;
+    if (cf_eps > 0.f) {
+      const float k = 1.0f - cf_eps * rs;  // std / (std + eps); 0 for a constant row (the reference's gradient is not finite there)
+      m2 = k > 0.f ? m2 / k : 0.f;
+    }
 #pragma unroll
     for (int it = 0; it < LN_MAXIT; ++it) {
       const int ch = lane + it * 64;
@@ -557,6 +566,40 @@ extern "C" int cvh_ln_seq_bwd(int dtype, const void* x, const void* dy, const fl
   hipStream_t st = (hipStream_t)stream;
   if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_seq_bwd_kernel<bf16_t>), dim3(nseq), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, stats, (bf16_t*)dx, part, p);
   else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_seq_bwd_kernel<float>), dim3(nseq), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, stats, (float*)dx, part, p);
+  else return -1;
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The reference's channel-first LayerNorm branch on a genuine feature map (cvnets/layers/normalization/layer_norm.py:53-66:
+// x.shape[1] == C, x.ndim > 2): statistics over the channels of every pixel, y = beta[c] + gamma[c] (x - u) / (std + eps).  On the NHWC
+// storage of the HIP path that is a row-wise normalisation of the [pixels][C] matrix with the (std + eps) denominator: the one-row-per-wave
+// kernels with the CF switch.  rstd[] holds 1 / (std + eps).
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int cvh_layernorm_cf_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    long long rows, int C, float eps, void* stream) {
+  if (C % 4 || C > 64 * 4 * LN_MAXIT || C <= 0 || eps <= 0.f) return -2;
+  if (rows <= 0) return 0;
+  long long g = (rows + 3) / 4;
+  if (g > 8192) g = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, true>), dim3((int)g), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, (size_t)rows, C, eps);
+  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_fwd_kernel<float, true>), dim3((int)g), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, (size_t)rows, C, eps);
+  else return -1;
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+/* part: cvh_ln_bwd_rows(rows) partial rows [2][C] of dgamma / dbeta, as cvh_layernorm_bwd leaves them */
+extern "C" int cvh_layernorm_cf_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                    float* part, long long rows, int C, float eps, void* stream) {
+  if (C % 4 || C > 64 * 4 * LN_MAXIT || C <= 0 || eps <= 0.f) return -2;
+  if (rows <= 0) return 0;
+  const int g = cvh_ln_bwd_rows(rows);
+  const size_t smem = (size_t)4 * 2 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CVH_DT_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(g), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (bf16_t*)dx, part, (size_t)rows, C, (const bf16_t*)nullptr, eps);
+  else if (dtype == CVH_DT_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(g), dim3(256), smem, st, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, part, (size_t)rows, C, (const float*)nullptr, eps);
   else return -1;
   CVH_CHECK_LAUNCH();
   return 0;

@@ -105,6 +105,8 @@ SIGNATURES = {
     "cvh_layernorm_fwd": [I, P, P, P, P, P, P, L, I, F, P],
     "cvh_layernorm_bwd": [I, P, P, P, P, P, P, P, L, I, P],
     "cvh_layernorm_bwd_res": [I, P, P, P, P, P, P, P, L, I, P, P],
+    "cvh_layernorm_cf_fwd": [I, P, P, P, P, P, P, L, I, F, P],
+    "cvh_layernorm_cf_bwd": [I, P, P, P, P, P, P, P, L, I, F, P],
     "cvh_ln_bwd_rows": [L],
     "cvh_ln_bwd_drop_ok": [I],
     "cvh_layernorm_bwd_res_drop": [I, P, P, P, P, P, P, P, L, I, P, P, F, P, U, P],

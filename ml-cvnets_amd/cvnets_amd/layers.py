@@ -136,7 +136,7 @@ class LayerNorm(nn.LayerNorm):
     channel-first branch (:53-66) is taken whenever ``x.shape[1] == C and x.ndim > 2`` — which also happens, by accident, for a
     [B', S, C] token tensor with S == C (MobileViT-S at 192x192, MobileViT-XXS at 128x128).  That case is reproduced bug-compatibly
     (cvh_ln_seq_*, ``reference_quirk = True``); set ``reference_quirk = False`` for the documented channel-last LayerNorm.  A
-    genuine NCHW feature map through this class is rejected (not on the hot path)."""
+    genuine [B, C, H, W] feature map takes the same branch per pixel over its channels (cvh_layernorm_cf_*)."""
 
     reference_quirk = True
 
@@ -149,8 +149,16 @@ class LayerNorm(nn.LayerNorm):
             b, s, _ = x.shape
             y = ops.layer_norm_tokens(x.reshape(b * s, c).contiguous(), self, (b, s, 1, 1, s, 1, s))
             return y.view(b, s, c)
+        if x.ndim == 4 and x.shape[1] == c:  # a genuine [B, C, H, W] feature map: the channel-first branch (layer_norm.py:53-66)
+            if c % 8:
+                raise NotImplementedError("channel-first LayerNorm: the NHWC storage pads C to a multiple of 8 (C % 8 == 0 needed)")
+            xm = ops.to_nhwc(x)
+            b, _, h, w = xm.shape
+            gamma = self.weight if self.weight is not None else torch.ones(c, device=xm.device)    # plumbing (elementwise_affine=False)
+            beta = self.bias if self.bias is not None else torch.zeros(c, device=xm.device)
+            return ops.fmap_of(ops.layer_norm_channel_first(ops.tokens_of(xm), gamma, beta, self.eps), b, h, w)
         if x.ndim > 2 and x.shape[1] == c and x.shape[-1] != c:
-            raise NotImplementedError("channel-first LayerNorm of a feature map is not on the HIP hot path")
+            raise NotImplementedError("channel-first LayerNorm is on the HIP hot path for 4-D feature maps (and S == C token tensors) only")
         if x.shape[-1] != c:
             raise NotImplementedError("LayerNorm is supported for channel-last format only")
         shp = x.shape

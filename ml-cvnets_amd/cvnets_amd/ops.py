@@ -1179,6 +1179,39 @@ class LayerNormSeqFn(torch.autograd.Function):
         return dx, dgb[:S], dgb[S:], None, None
 
 
+class LayerNormChannelFirstFn(torch.autograd.Function):
+    """cvnets/layers/normalization/layer_norm.py:53-66 on a genuine feature map: per pixel, over its channels,
+    (x - mean) / (biased std + eps) * weight[c] + bias[c].  `x` is the [pixels, C] token matrix of the NHWC map."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _check_dev(x)
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        mr = _f32(2, x.device, rows)
+        _lib.call("cvh_layernorm_cf_fwd", _dt(x), _p(x), _p(gamma), _p(beta), _p(y), _p(mr[0]), _p(mr[1]), rows, C, float(eps), _stream())
+        ctx.eps = float(eps)
+        ctx.save_for_backward(x, gamma, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, mr = ctx.saved_tensors
+        rows, C = x.shape
+        dout = dout.contiguous()
+        R = _lib.query("cvh_ln_bwd_rows", rows)
+        part = _f32(R * 2 * C, x.device)
+        dx = torch.empty_like(x)
+        _lib.call("cvh_layernorm_cf_bwd", _dt(x), _p(x), _p(dout), _p(gamma), _p(mr[0]), _p(mr[1]), _p(dx), _p(part), rows, C, ctx.eps, _stream())
+        dgb = _f32(2 * C, x.device)
+        _lib.call("cvh_sum_partials", _p(part), R, 2 * C, 2 * C, _p(dgb), 1.0, 0, _stream())
+        return dx, dgb[:C], dgb[C:], None
+
+
+def layer_norm_channel_first(x2d, gamma, beta, eps):
+    return LayerNormChannelFirstFn.apply(x2d.contiguous(), gamma, beta, float(eps))
+
+
 def layer_norm_tokens(x2d, ln, seqmap):
     """LayerNorm of a token matrix whose sequences are described by `seqmap`, reproducing WHICH branch the reference's LayerNorm
     takes for the equivalent [B', S, C] tensor: channel-last F.layer_norm normally, the channel-first formula when S == C

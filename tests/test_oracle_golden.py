@@ -187,3 +187,26 @@ def test_oracle_with_dropout_factors_matches_reference_fixture():
             assert np.allclose(grads[key[6:]].numpy(), gold[key], rtol=1e-3, atol=1e-6), key
     plain, _, _, _ = orc.train_step(sd, x, y, mode="xx_small")
     assert not np.allclose(plain.numpy(), gold["logits_train"], rtol=1e-2, atol=1e-3)  # the masks matter
+
+
+def test_channel_first_layernorm_fixture_matches_the_written_out_formula():
+    """tests/golden/layernorm_channel_first.npz (reference outputs, oracle/make_layer_fixtures.py) against layer_norm.py:53-66 written out
+    in float64 on the same seeded tensors: pins the fixture on machines without the reference."""
+    import os
+
+    import numpy as np
+    import torch
+    from oracle.make_layer_fixtures import LN_CF_CASES, ln_cf_tensors
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "layernorm_channel_first.npz"))
+    for name, B, C, H, W in LN_CF_CASES:
+        x, w, b, g = (t.double() for t in ln_cf_tensors(name, B, C, H, W))
+        x.requires_grad_(True)
+        w.requires_grad_(True)
+        b.requires_grad_(True)
+        s, u = torch.std_mean(x, dim=1, keepdim=True, unbiased=False)
+        y = (x - u) / (s + 1e-5) * w.view(1, C, 1, 1) + b.view(1, C, 1, 1)
+        (y * g).sum().backward()
+        for key, t in (("_y", y), ("_dx", x.grad), ("_dw", w.grad), ("_db", b.grad)):
+            ref = torch.from_numpy(gold[name + key]).double()
+            assert float((t.detach() - ref).norm() / ref.norm()) < 1e-5, (name, key)

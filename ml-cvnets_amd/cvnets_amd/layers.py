@@ -557,16 +557,28 @@ class LinearSelfAttention(nn.Module):
 
     def forward(self, x: Tensor, x_prev: Optional[Tensor] = None, patch_hw: Tuple[int, int] = (2, 2), residual: Optional[Tensor] = None,
                 *args, **kwargs) -> Tensor:
-        if x_prev is not None:
-            raise NotImplementedError("linear cross-attention (x_prev) is not on the HIP hot path")
         if self.attn_dropout.p > 0.0 and self.training:
             raise NotImplementedError("dropout on the context scores is not on the HIP hot path (mitv2.attn_dropout defaults to 0)")
         C = self.embed_dim
         conv = self.qkv_proj.block.conv
         w, b = conv.weight, conv.bias
-        wp = torch.cat((w[1:], w[:1], w.new_zeros((7,) + tuple(w.shape[1:]))), dim=0)  # plumbing: [2C+8, C, 1, 1] row permutation
-        bp = torch.cat((b[1:], b[:1], b.new_zeros(7)), dim=0) if b is not None else None
-        kvq = ops.conv_bn_act(ops.to_nhwc(x), wp, bp)
+        if x_prev is not None:
+            # _forward_cross_attn (linear_attention.py:163-207): query and key are projected from x_prev, the value from x; the softmax and
+            # the context sum run over the previous frame's patches.  x_prev arrives as the previous frame's FEATURE MAP (the caller folds
+            # the reference's [B, C, P, M] tensor); with M == N the fused kernel takes [key(x_prev) | value(x) | query(x_prev)] as it takes
+            # the self-attention projection - two GEMMs and a channel concatenation (torch plumbing) instead of one GEMM.
+            xp = ops.to_nhwc(x_prev)
+            if tuple(xp.shape) != tuple(x.shape):
+                raise NotImplementedError("linear cross-attention on the HIP path needs x_prev with the current frame's patch grid (M == N)")
+            wkq = torch.cat((w[1:C + 1], w[:1], w.new_zeros((7,) + tuple(w.shape[1:]))), dim=0)  # plumbing: [C+8, C, 1, 1]: key | query | 0
+            bkq = torch.cat((b[1:C + 1], b[:1], b.new_zeros(7)), dim=0) if b is not None else None
+            kq = ops.conv_bn_act(xp, wkq, bkq)
+            v = ops.conv_bn_act(ops.to_nhwc(x), w[C + 1:], b[C + 1:] if b is not None else None)
+            kvq = torch.cat((kq[:, :C], v, kq[:, C:]), dim=1).contiguous(memory_format=torch.channels_last)  # plumbing
+        else:
+            wp = torch.cat((w[1:], w[:1], w.new_zeros((7,) + tuple(w.shape[1:]))), dim=0)  # plumbing: [2C+8, C, 1, 1] row permutation
+            bp = torch.cat((b[1:], b[:1], b.new_zeros(7)), dim=0) if b is not None else None
+            kvq = ops.conv_bn_act(ops.to_nhwc(x), wp, bp)
         out = ops.linear_attention(kvq, C, patch_hw[0], patch_hw[1])
         return self.out_proj(out, residual=residual)
 

@@ -395,12 +395,11 @@ class LinearAttnFFN(nn.Module):
             self.__class__.__name__, self.embed_dim, self.ffn_dim, self.std_dropout, self.ffn_dropout, self.attn_fn_name, self.norm_name)
 
     def forward(self, x: Tensor, x_prev: Optional[Tensor] = None, patch_hw: Tuple[int, int] = (2, 2), *args, **kwargs) -> Tensor:
-        if x_prev is not None:
-            raise NotImplementedError("linear cross-attention (x_prev) is not on the HIP hot path")
         x = ops.to_nhwc(x)
         norm, attn, drop = self.pre_norm_attn[0], self.pre_norm_attn[1], self.pre_norm_attn[2]
         droppy = self.training and drop.p > 0.0
-        y = attn(norm(x), patch_hw=patch_hw, residual=None if droppy else x)  # residual rides in out_proj's GEMM epilogue
+        # x_prev (transformer.py:253-259): the previous frame's feature map, NOT normalised, is the query / key source
+        y = attn(norm(x), x_prev=x_prev, patch_hw=patch_hw, residual=None if droppy else x)  # residual rides in out_proj's GEMM epilogue
         x = ops.add(x, drop(y)) if droppy else y
         norm, fc1, drop1, fc2, drop2 = (self.pre_norm_ffn[i] for i in range(5))
         h = drop1(fc1(norm(x)))
@@ -486,7 +485,36 @@ class MobileViTBlockv2(nn.Module):
             fm = layer(fm, patch_hw=phw) if isinstance(layer, LinearAttnFFN) else layer(fm)
         return self.conv_proj(fm)
 
+    def _fold(self, patches: Tensor, H: int, W: int) -> Tensor:
+        """[B, C, P, N] of the reference (F.unfold order: P = i * patch_w + j, N = nh * n_w + nw; mobilevit_block.py:526-540) -> [B, C, H, W]"""
+        B, C, P, N = patches.shape
+        ph, pw = self.patch_h, self.patch_w
+        if P != ph * pw or N != (H // ph) * (W // pw):
+            raise NotImplementedError("x_prev must hold the current frame's patch grid ([B, C, patch area, patches])")
+        return patches.reshape(B, C, ph, pw, H // ph, W // pw).permute(0, 1, 4, 2, 5, 3).reshape(B, C, H, W)  # plumbing
+
+    def _unfold(self, fm: Tensor) -> Tensor:
+        B, C, H, W = fm.shape
+        ph, pw = self.patch_h, self.patch_w
+        return fm.reshape(B, C, H // ph, ph, W // pw, pw).permute(0, 1, 3, 5, 2, 4).reshape(B, C, ph * pw, (H // ph) * (W // pw))  # plumbing
+
+    def forward_temporal(self, x: Tensor, x_prev: Optional[Tensor], *args, **kwargs) -> Tuple[Tensor, Tensor]:
+        """mobilevit_block.py:628-655: every LinearAttnFFN takes its query / key from the previous frame's patches `x_prev` ([B, C, P, N] as
+        this method returned them; None: first frame, plain self-attention); returns (feature map, patches after the global layers).  The
+        HIP kernels work on the feature map itself, so x_prev is folded once and the returned patches are unfolded once (index
+        permutations, torch plumbing)."""
+        x = self.resize_input_if_needed(ops.to_nhwc(x))
+        fm = self.local_rep(x)
+        B, C, H, W = fm.shape
+        prev = None
+        if x_prev is not None:
+            prev = ops.to_nhwc(self._fold(x_prev, H, W).to(fm.dtype))
+        phw = (self.patch_h, self.patch_w)
+        for layer in self.global_rep:
+            fm = layer(fm, x_prev=prev, patch_hw=phw) if isinstance(layer, LinearAttnFFN) else layer(fm)
+        return self.conv_proj(fm), self._unfold(fm)
+
     def forward(self, x, *args, **kwargs):
-        if isinstance(x, tuple):
-            raise NotImplementedError("temporal (x, x_prev) MobileViTv2 blocks are not on the HIP hot path")
+        if isinstance(x, tuple) and len(x) == 2:
+            return self.forward_temporal(x[0], x[1])
         return self.forward_spatial(x)

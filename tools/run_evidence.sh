@@ -27,3 +27,13 @@ python tools/pmc_util.py $O/pmc_lds > $O/pmc_lds.txt 2>&1; head -10 $O/pmc_lds.t
 # bench.py's N > 1 code path on one GPU (single-rank world, collectives issued anyway through the own communicator, inside the captured graph)
 (CVH_DDP_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-probe 2>&1 | grep "^{" | tail -1) > $O/bench_force_collectives.json; cut -c1-200 $O/bench_force_collectives.json
 find $O -name "*counter_collection.csv" -size +8M -delete; du -sh $O
+# BASELINE configs 3-5 (ViT-B/16, CLIP ViT-B/16, MobileViTv2-1.0 at 384 x 384): the JSON lines and, per model, a kernel trace + the two traffic passes
+(timeout 900 python tools/bench_models.py --models vit_base,clip,mobilevitv2 --batch vit_base=512,clip=256,mobilevitv2=128 --steps 10 --warmup 3 2>/dev/null | grep "^{") > $O/bench_models.jsonl; cut -c1-260 $O/bench_models.jsonl
+for m in vit_base:512 clip:256 mobilevitv2:128; do
+  M=${m%%:*}; B=${m##*:}
+  rm -rf $O/mprof_$M; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mprof_$M -o bench -- python tools/bench_models.py --models $M --batch $M=$B --steps 4 --warmup 2 > $O/mprof_$M.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/mpmc_${M}_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/mpmc_${M}_$c -o pmc -- python tools/bench_models.py --models $M --batch $M=$B --steps 2 --warmup 1 > $O/mpmc_${M}_$c.log 2>&1; done
+  python tools/model_prof_summary.py $M $B $O/mprof_$M $O/mpmc_${M}_FETCH_SIZE $O/mpmc_${M}_WRITE_SIZE > $O/${M}_prof_summary.txt 2>&1; head -8 $O/${M}_prof_summary.txt | cut -c1-200
+  cp $O/mprof_$M/bench_kernel_stats.csv $O/${M}_kernel_stats.csv 2>/dev/null
+done
+find $O -name "*counter_collection.csv" -size +8M -delete; find $O -name "*kernel_trace.csv" -size +8M -delete; du -sh $O

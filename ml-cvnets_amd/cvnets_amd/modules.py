@@ -286,6 +286,8 @@ class MobileViTBlock(nn.Module):
     def forward_spatial(self, x: Tensor) -> Tensor:
         x = ops.to_nhwc(x)
         res = x
+        if self.fusion is not None:  # x feeds local_rep AND the fusion concat: their two gradients meet in cvh_add (ops.Fork2)
+            x, res = ops.fork2(x)
         fm = self.local_rep.conv_3x3(x)
         fm = self.local_rep.conv_1x1(fm)
         B, d, H, W = fm.shape

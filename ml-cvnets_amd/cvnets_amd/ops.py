@@ -1400,6 +1400,32 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
+class Fork2(torch.autograd.Function):
+    """x -> (x, x) for a feature map with two consumers inside one module (MobileViTBlock: local_rep and the concat in front of the fusion
+    conv, cvnets/modules/mobilevit_block.py:270-287).  Forward is free (two aliases); backward sums the two gradients with cvh_add —
+    otherwise autograd's own accumulation does it with an ATen kernel inside the captured step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        if g1.shape != g2.shape or g1.stride() != g2.stride() or g1.dtype != g2.dtype or not g1.is_cuda:
+            return g1 + g2  # plumbing (foreign layouts)
+        y = torch.empty_like(g1)
+        _lib.call("cvh_add", _dt(g1), _p(g1), _p(g2), _p(y), g1.numel(), _stream())
+        return y
+
+
+def fork2(x):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return Fork2.apply(x)
+
+
 def add(a, b):
     return AddFn.apply(a, b)
 

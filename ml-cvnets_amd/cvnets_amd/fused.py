@@ -239,6 +239,9 @@ class InvertedResidualFn(torch.autograd.Function):
         ctx.has_osum = osum is not None
         ctx.use_x = use_x
         ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, *(gram if gram is not None else (None, None)))
+        # (the side outputs carry no gradient: without this the engine hands backward a freshly zero-filled tensor for each of them —
+        # an ATen fill kernel per block inside the captured step)
+        ctx.set_materialize_grads(False)
         if gs is not None:
             ctx.mark_non_differentiable(gs)
             return out, None, gs

@@ -427,10 +427,14 @@ def _conv_gemm(src1, src2, C1, C2, wp, out, B, H, W, Ho, Wo, KH, KW, stride, pad
               _p(stats_part), _stream())
 
 
+_UNIT_COEFFS = {}
+
+
 def _unit_coeffs(C, device):
-    ones = torch.ones(C, dtype=torch.float32, device=device)  # plumbing: tiny constant vectors
-    zeros = torch.zeros(C, dtype=torch.float32, device=device)
-    return ones, zeros
+    key = (int(C), str(device))
+    if key not in _UNIT_COEFFS:  # tiny constant vectors, made once per width (not two fill kernels per call)
+        _UNIT_COEFFS[key] = (torch.ones(C, dtype=torch.float32, device=device), torch.zeros(C, dtype=torch.float32, device=device))
+    return _UNIT_COEFFS[key]
 
 
 def _act_backward(pre: torch.Tensor, dout: torch.Tensor, act: int, rows: int, C: int) -> torch.Tensor:
@@ -766,6 +770,7 @@ class ConvBNAct(torch.autograd.Function):
             gs = _bn_apply_out(y, stats, act, residual, out, M, Cout, gamma, training)
             ctx.save_for_backward(x, x2, weight, y, stats, gamma)
             if gs is not None:
+                ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the side output
                 ctx.mark_non_differentiable(gs)
                 return out, gs
             return out
@@ -874,6 +879,7 @@ class StemConvBNAct(torch.autograd.Function):
         ctx.beta = beta
         ctx.save_for_backward(x, weight, y, stats, gamma)
         if gs is not None:
+            ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the side output
             ctx.mark_non_differentiable(gs)
             return out, gs
         return out

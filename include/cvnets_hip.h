@@ -354,6 +354,8 @@ int cvh_lerp_multi(const long long* table, int n_tensors, long long total, float
  * caller's.  bwd: dlogits = *gout * (softmax - (1-eps) * onehot - eps/M), *gout = upstream gradient / number of valid rows. */
 int cvh_ce_fwd(int dtype, const void* logits, const long long* labels, float label_smoothing, long long ignore_index, float* loss_rows,
                float* lse, int N, int M, void* stream);
+/* the 'mean' reduction of the same call in one launch: out2[0] = sum(loss_rows) / max(1, #labels != ignore_index), out2[1] = 1 / that count */
+int cvh_ce_mean(const float* loss_rows, const long long* labels, long long ignore_index, float* out2, int N, void* stream);
 int cvh_ce_bwd(int dtype, const void* logits, const long long* labels, const float* lse, const float* gout, float label_smoothing,
                long long ignore_index, void* dlogits, int N, int M, void* stream);
 

@@ -431,6 +431,41 @@ extern "C" int cvh_ce_fwd(int dtype, const void* logits, const long long* labels
   CVH_CHECK_LAUNCH();
   return 0;
 }
+// loss = sum(loss_rows) / max(1, #rows whose label is not ignore_index) in ONE launch (F.cross_entropy's 'mean' reduction,
+// loss_fn/classification/cross_entropy.py:65-92); out[0] = loss, out[1] = 1 / that count (the backward's scale).  One workgroup, fixed-order tree.
+__global__ __launch_bounds__(1024) void ce_mean_kernel(const float* __restrict__ rows, const long long* __restrict__ labels, long long ignore_index,
+                                                       float* __restrict__ out, int N) {
+  __shared__ float ssum[1024];
+  __shared__ int scnt[1024];
+  float s = 0.f;
+  int c = 0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    s += rows[i];
+    c += labels[i] != ignore_index ? 1 : 0;
+  }
+  ssum[threadIdx.x] = s;
+  scnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + st];
+      scnt[threadIdx.x] += scnt[threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float n = (float)(scnt[0] > 0 ? scnt[0] : 1);
+    out[0] = ssum[0] / n;
+    out[1] = 1.0f / n;
+  }
+}
+extern "C" int cvh_ce_mean(const float* loss_rows, const long long* labels, long long ignore_index, float* out2, int N, void* stream) {
+  if (N <= 0) return -2;
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_rows, labels, ignore_index, out2, N);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int cvh_ce_bwd(int dtype, const void* logits, const long long* labels, const float* lse, const float* gout, float label_smoothing,
                           long long ignore_index, void* dlogits, int N, int M, void* stream) {
   if (N <= 0 || M <= 0) return -2;

@@ -93,6 +93,7 @@ SIGNATURES = {
     "cvh_lerp_multi": [P, I, L, F, P],
     "cvh_ce_fwd": [I, P, P, F, L, P, P, I, I, P],
     "cvh_ce_bwd": [I, P, P, P, P, F, L, P, I, I, P],
+    "cvh_ce_mean": [P, P, L, P, I, P],
     "cvh_ce_soft_fwd": [I, P, P, F, P, P, P, I, I, P],
     "cvh_ce_soft_bwd": [I, P, P, P, P, P, F, P, I, I, P],
     "cvh_gn_chunks": [I, I, I],

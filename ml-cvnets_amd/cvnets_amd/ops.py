@@ -1747,9 +1747,16 @@ class CrossEntropyFn(torch.autograd.Function):
         N, M = logits.shape
         rows, lse = _f32(N, logits.device), _f32(N, logits.device)
         _lib.call("cvh_ce_fwd", _dt(logits), _p(logits), _p(labels), float(label_smoothing), int(ignore_index), _p(rows), _p(lse), N, M, _stream())
-        n_valid = (labels != ignore_index).sum().clamp_(min=1).float()  # plumbing: label bookkeeping
-        ctx.save_for_backward(logits, labels, lse, n_valid)
         ctx.cfg = (float(label_smoothing), int(ignore_index))
+        if N <= (1 << 20):  # classification batches: mean over the non-ignored rows and its reciprocal count in one launch
+            out2 = _f32(2, logits.device)
+            _lib.call("cvh_ce_mean", _p(rows), _p(labels), int(ignore_index), _p(out2), N, _stream())
+            ctx.save_for_backward(logits, labels, lse, out2[1:2])
+            ctx.inv = True
+            return out2[0]
+        n_valid = (labels != ignore_index).sum().clamp_(min=1).float()  # plumbing: label bookkeeping (dense-prediction sized label maps)
+        ctx.save_for_backward(logits, labels, lse, n_valid)
+        ctx.inv = False
         return rows.sum() / n_valid  # plumbing: N-element reduction
 
     @staticmethod
@@ -1757,7 +1764,7 @@ class CrossEntropyFn(torch.autograd.Function):
         logits, labels, lse, n_valid = ctx.saved_tensors
         eps, ignore = ctx.cfg
         N, M = logits.shape
-        gout = (g.float() / n_valid).reshape(1)  # plumbing: scalar
+        gout = (g.float() * n_valid if ctx.inv else g.float() / n_valid).reshape(1)  # plumbing: scalar (n_valid holds 1 / count when ctx.inv)
         dlogits = torch.empty_like(logits)
         _lib.call("cvh_ce_bwd", _dt(logits), _p(logits), _p(labels), _p(lse), _p(gout), eps, ignore, _p(dlogits), N, M, _stream())
         return dlogits, None, None, None

@@ -147,6 +147,11 @@ int cvh_bn_bwd_reduce(int dtype, const void* x, const void* dout, const float* s
                       const float* invstd, int act, long long rows, int C, float* part, void* stream);
 int cvh_bn_bwd_finalize(const float* part, int R, int C, double count, const float* gamma, const float* mean, const float* invstd,
                         int training, int accumulate, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream);
+/* the same for partial rows whose second sum was taken against the BatchNorm's OUTPUT out = gamma * xhat + beta instead of xhat
+ * (cvh_ir_exp_bwd_s forms them where `out` is the next block's input): sum dz * xhat = (sum dz * out - beta * sum dz) / gamma */
+int cvh_bn_bwd_finalize_out(const float* part, int R, int C, double count, const float* gamma, const float* beta, const float* mean,
+                            const float* invstd, int training, int accumulate, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
+                            void* stream);
 int cvh_bn_bwd_apply(int dtype, const void* x, const void* dout, const float* scale, const float* shift, int act, const float* ca,
                      const float* cb, const float* cc, void* dx, long long rows, int C, void* stream);
 
@@ -254,6 +259,11 @@ int cvh_ir_red_fwd(int dtype, const void* y2, const float* scale, const float* s
 int cvh_ir_exp_bwd_rows(long long M, int hid, int Cin);
 int cvh_ir_exp_bwd(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
                    float* p_part, long long M, int hid, int Cin, void* stream);
+/* cvh_ir_exp_bwd that also leaves s_part[cvh_ir_exp_bwd_rows][2][Cin]: per workgroup, the column sums of dX (as stored) and of dX * x —
+ * the statistics the BatchNorm backward of the PREVIOUS block's projection (whose output x is) needs of its incoming gradient dX
+ * (cvnets/modules/mobilenetv2.py:231-235 chained: block k's output is block k+1's input); s_part == NULL: cvh_ir_exp_bwd */
+int cvh_ir_exp_bwd_s(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
+                     float* p_part, float* s_part, long long M, int hid, int Cin, void* stream);
 int cvh_bn_dw_combine(const float* P, const float* w, const float* G, const float* s, const float* coef, float* dw, int N, int K,
                       int accumulate, void* stream);
 

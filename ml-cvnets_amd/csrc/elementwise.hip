@@ -537,7 +537,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int R, int C, double count, const float* __restrict__ gamma,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd, int training, int accumulate,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ca,
-                                                               float* __restrict__ cb, float* __restrict__ cc) {
+                                                               float* __restrict__ cb, float* __restrict__ cc,
+                                                               const float* __restrict__ out_basis_beta = nullptr) {
   __shared__ double red[64][2][16];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
@@ -554,7 +555,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     __syncthreads();
   }
   if (rl == 0 && c < C) {
-    const double s1 = red[0][0][threadIdx.x & 15], s2 = red[0][1][threadIdx.x & 15];
+    const double s1 = red[0][0][threadIdx.x & 15];
+    double s2 = red[0][1][threadIdx.x & 15];
+    if (out_basis_beta) {  // the second sum arrived as sum dz * out with out = gamma * xhat + beta (the BatchNorm's own output, no activation)
+      const double g0 = gamma ? (double)gamma[c] : 1.0;
+      s2 = g0 != 0.0 ? (s2 - (double)out_basis_beta[c] * s1) / g0 : 0.0;
+    }
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     const double g = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c], mu = (double)mean[c];
@@ -1085,6 +1091,18 @@ extern "C" int cvh_bn_bwd_finalize(const float* part, int R, int C, double count
                                    int training, int accumulate, float* dgamma, float* dbeta, float* ca, float* cb, float* cc, void* stream) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, mean, invstd, training,
                      accumulate, dgamma, dbeta, ca, cb, cc);
+  CVH_CHECK_LAUNCH();
+  return 0;
+}
+/* cvh_bn_bwd_finalize for partial rows (sum dz, sum dz * OUT) in which the second sum was taken against the BatchNorm's own output
+ * out = gamma * xhat + beta (as stored) instead of xhat — what the kernel that PRODUCES dz can form when `out` is its input
+ * (cvh_ir_exp_bwd_s): sum dz * xhat = (sum dz * out - beta * sum dz) / gamma, applied after the reduction in double. */
+extern "C" int cvh_bn_bwd_finalize_out(const float* part, int R, int C, double count, const float* gamma, const float* beta, const float* mean,
+                                       const float* invstd, int training, int accumulate, float* dgamma, float* dbeta, float* ca, float* cb,
+                                       float* cc, void* stream) {
+  if (beta == nullptr || gamma == nullptr) return -2;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, part, R, C, count, gamma, mean, invstd, training,
+                     accumulate, dgamma, dbeta, ca, cb, cc, beta);
   CVH_CHECK_LAUNCH();
   return 0;
 }

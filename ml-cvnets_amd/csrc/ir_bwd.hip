@@ -29,6 +29,7 @@ struct IrExpBwdParams {
   const bf16_t* res;    // [M][Cin] or nullptr
   bf16_t* dx;           // [M][Cin]
   float* ppart;         // [grid][hid][Cin]
+  float* spart;         // [grid][2][Cin] or nullptr: column sums of dX and of dX * x over the workgroup's rows (dX as stored)
   int M, hid, Cin, ntiles;
 };
 
@@ -101,6 +102,15 @@ __global__ __launch_bounds__(IB_THREADS) void ir_exp_bwd_kernel(IrExpBwdParams p
   for (int i = 0; i < HPW; ++i)
 #pragma unroll
     for (int c = 0; c < CB; ++c) pacc[i][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // column sums of the stored dX and of dX * x (x = this block's input = the previous block's output): what the BatchNorm backward of the
+  // PREVIOUS block's projection needs of its incoming gradient (sum dout, sum dout * xhat with xhat = (x - beta) / gamma there), so that block
+  // does not read dout and its y3 once more for them.  A wave keeps the same channels in every tile: per-lane accumulators.
+  const bool want_s = p.spart != nullptr;
+  float ss1[NBLK][4], ss2[NBLK][4];
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ss1[i][e] = ss2[i][e] = 0.f;
 
   int t = blockIdx.x, cur = 0;
   if (t < p.ntiles) {
@@ -154,7 +164,16 @@ __global__ __launch_bounds__(IB_THREADS) void ir_exp_bwd_kernel(IrExpBwdParams p
             v[0] += bf2f((uint16_t)(rr.x & 0xffff)); v[1] += bf2f((uint16_t)(rr.x >> 16));
             v[2] += bf2f((uint16_t)(rr.y & 0xffff)); v[3] += bf2f((uint16_t)(rr.y >> 16));
           }
-          *reinterpret_cast<uint2*>(p.dx + (size_t)m * CIN + c) = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+          const uint2 o = make_uint2(f2bf_pk(v[0], v[1]), f2bf_pk(v[2], v[3]));
+          *reinterpret_cast<uint2*>(p.dx + (size_t)m * CIN + c) = o;
+          if (want_s) {
+            const uint2 xx = *reinterpret_cast<const uint2*>(xt + (16 * mb + l15) * XP + c);
+            const float d0 = bf2f((uint16_t)(o.x & 0xffff)), d1 = bf2f((uint16_t)(o.x >> 16)), d2 = bf2f((uint16_t)(o.y & 0xffff)),
+                        d3 = bf2f((uint16_t)(o.y >> 16));
+            ss1[i][0] += d0; ss1[i][1] += d1; ss1[i][2] += d2; ss1[i][3] += d3;
+            ss2[i][0] += d0 * bf2f((uint16_t)(xx.x & 0xffff)); ss2[i][1] += d1 * bf2f((uint16_t)(xx.x >> 16));
+            ss2[i][2] += d2 * bf2f((uint16_t)(xx.y & 0xffff)); ss2[i][3] += d3 * bf2f((uint16_t)(xx.y >> 16));
+          }
         }
       }
     }
@@ -179,6 +198,37 @@ __global__ __launch_bounds__(IB_THREADS) void ir_exp_bwd_kernel(IrExpBwdParams p
     if (tn < p.ntiles) store_tile(tiles + (cur ^ 1) * TILE);
     __syncthreads();
     cur ^= 1;
+  }
+
+  if (want_s) {  // (the loop ended with a barrier: the tiles are free) rows of a wave: lanes l15; waves of one channel block: fixed order
+    float* red = reinterpret_cast<float*>(tiles);  // [8 waves][2][NBLK * 16]
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = ss1[i][e], b = ss2[i][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          a += __shfl_xor(a, m, 64);
+          b += __shfl_xor(b, m, 64);
+        }
+        if (l15 == 0) {
+          red[(wave * 2 + 0) * (NBLK * 16) + 16 * i + 4 * l4 + e] = a;
+          red[(wave * 2 + 1) * (NBLK * 16) + 16 * i + 4 * l4 + e] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * CIN) {
+      const int k = tid / CIN, c = tid - k * CIN, cb = c >> 4;
+      float sum = 0.f;
+      for (int w = 0; w < 8; ++w) {
+        const int j0 = w * NBLK;
+        if (j0 >= 4 * CB) break;
+        const int mb = j0 / CB, cb0 = j0 - mb * CB;
+        if (cb >= cb0 && cb < cb0 + NBLK) sum += red[(w * 2 + k) * (NBLK * 16) + 16 * (cb - cb0) + (c & 15)];
+      }
+      p.spart[((size_t)blockIdx.x * 2 + k) * CIN + c] = sum;
+    }
   }
 
   float* __restrict__ out = p.ppart + (size_t)blockIdx.x * HID * CIN;
@@ -211,14 +261,20 @@ extern "C" int cvh_ir_exp_bwd_rows(long long M, int hid, int Cin) {
   return nt < wgs ? (int)nt : wgs;
 }
 
+extern "C" int cvh_ir_exp_bwd_s(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
+                                float* p_part, float* s_part, long long M, int hid, int Cin, void* stream);
 extern "C" int cvh_ir_exp_bwd(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
                               float* p_part, long long M, int hid, int Cin, void* stream) {
+  return cvh_ir_exp_bwd_s(dtype, g, x, wcat, bias, residual, dx, p_part, nullptr, M, hid, Cin, stream);
+}
+extern "C" int cvh_ir_exp_bwd_s(int dtype, const void* g, const void* x, const void* wcat, const float* bias, const void* residual, void* dx,
+                                float* p_part, float* s_part, long long M, int hid, int Cin, void* stream) {
   if (dtype != CVH_DT_BF16) return -1;
   const int rows = cvh_ir_exp_bwd_rows(M, hid, Cin);
   if (rows <= 0) return -2;
   IrExpBwdParams p;
   p.g = reinterpret_cast<const bf16_t*>(g); p.x = reinterpret_cast<const bf16_t*>(x); p.wcat = reinterpret_cast<const bf16_t*>(wcat);
-  p.bias = bias; p.res = reinterpret_cast<const bf16_t*>(residual); p.dx = reinterpret_cast<bf16_t*>(dx); p.ppart = p_part;
+  p.bias = bias; p.res = reinterpret_cast<const bf16_t*>(residual); p.dx = reinterpret_cast<bf16_t*>(dx); p.ppart = p_part; p.spart = s_part;
   p.M = (int)M; p.hid = hid; p.Cin = Cin; p.ntiles = (int)((M + IB_TM - 1) / IB_TM);
   cvh_family_tally(3, (long long)M * (hid + Cin * (residual != nullptr ? 3 : 2)) * 2);
   hipStream_t st = (hipStream_t)stream;

@@ -46,6 +46,7 @@ SIGNATURES = {
     "cvh_ir_red_fwd_rows": [L, I, I],
     "cvh_ir_red_fwd": [I, P, P, P, I, P, P, P, L, I, I, P],
     "cvh_ir_exp_bwd": [I, P, P, P, P, P, P, P, L, I, I, P],
+    "cvh_ir_exp_bwd_s": [I, P, P, P, P, P, P, P, P, L, I, I, P],
     "cvh_stem_conv_fwd": [I, P, I, P, P, P, I, I, I, I, P],
     "cvh_stem_conv_dw": [I, P, P, P, I, I, I, I, P],
     "cvh_gemm_dw": [I, P, P, P, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, I, P],
@@ -67,6 +68,7 @@ SIGNATURES = {
     "cvh_bn_apply_gram": [I, P, P, P, I, P, P, L, I, P, I, P, P],
     "cvh_bn_bwd_reduce": [I, P, P, P, P, P, P, I, L, I, P, P],
     "cvh_bn_bwd_finalize": [P, I, I, D, P, P, P, I, I, P, P, P, P, P, P],
+    "cvh_bn_bwd_finalize_out": [P, I, I, D, P, P, P, P, I, I, P, P, P, P, P, P],
     "cvh_bn_bwd_apply": [I, P, P, P, P, I, P, P, P, P, L, I, P],
     "cvh_colsum": [I, P, L, I, P, P, F, I, P],
     "cvh_reduce_multi": [P, I, P],

@@ -238,6 +238,7 @@ class InvertedResidualFn(torch.autograd.Function):
             _lib.call("cvh_axpb", _p(b3), float(M2), _p(gram[1]) if use_res else None, _p(osum), Cout, _stream())
         ctx.has_osum = osum is not None
         ctx.use_x = use_x
+        ctx.out_id = (out.data_ptr(), out._version)  # to recognise statistics handed back by the consumer of exactly this tensor
         ctx.save_for_backward(x, w1, wd, w3, g1, g2, g3, y1, y2, y3, st1, st2, st3, *(gram if gram is not None else (None, None)))
         # (the side outputs carry no gradient: without this the engine hands backward a freshly zero-filled tensor for each of them —
         # an ATen fill kernel per block inside the captured step)
@@ -267,7 +268,11 @@ class InvertedResidualFn(torch.autograd.Function):
         if Rp > 0:
             # BatchNorm of the projection conv: statistics pass over the narrow (dout, y3) only — dy3 = ca dout + cb y3 + cc is formed by the
             # consumer on load; then dW3, g2 and (sum g2, sum g2*xhat2) from ONE pass over y2 (csrc/ir_pb.hip)
-            coef3, dg3, db3 = ops._bn_backward_coeffs(y3, dout, st3, g3, ACT_NONE, M2, Cout, training, beta=pb3)
+            handed = None
+            if ops._BN_HANDOVER and training and not use_res and pb3 is not None and dt == torch.bfloat16:
+                # the next block's expansion backward wrote dout AND its column sums against this block's output (cvh_ir_exp_bwd_s)
+                handed = ops.take_grad_stats(dout, Cout, M2, *ctx.out_id)
+            coef3, dg3, db3 = ops._bn_backward_coeffs(y3, dout, st3, g3, ACT_NONE, M2, Cout, training, beta=pb3, handed=handed)
             part = _f32(Rp * 2 * hid, dev)
             dw_part = _f32(Rp * Cout * hid, dev)
             wp3t = ops.pack_weight(w3, dt, 1)  # alive across the launch (uncached packs are temporaries)
@@ -327,8 +332,11 @@ class InvertedResidualFn(torch.autograd.Function):
             R1 = _lib.query("cvh_ir_exp_bwd_rows", M1, hid, Cin) if (_IR_EXP_FUSED and dt == torch.bfloat16 and w1.shape[1] == Cin) else 0
             if R1 > 0:  # dX1 and the raw dW1 product g1^T x from ONE pass over g1 (csrc/ir_bwd.hip)
                 ppart = _f32(R1 * hid * Cin, dev)
-                _lib.call("cvh_ir_exp_bwd", _dt(g1t), _p(g1t), _p(x), _p(wcat), _p(bias), _p(dout if use_res else None), _p(dx), _p(ppart), M1,
-                          hid, Cin, _stream())
+                spart = _f32(R1 * 2 * Cin, dev) if ops._BN_HANDOVER else None
+                _lib.call("cvh_ir_exp_bwd_s", _dt(g1t), _p(g1t), _p(x), _p(wcat), _p(bias), _p(dout if use_res else None), _p(dx), _p(ppart),
+                          _p(spart), M1, hid, Cin, _stream())
+                if spart is not None:  # (sum dX, sum dX * x) for the BatchNorm backward of the block whose output x is
+                    ops.offer_grad_stats(dx, spart, R1, Cin, M1, x)
                 P1 = _f32(hid * Cin, dev)
                 _lib.call("cvh_sum_partials", _p(ppart), R1, hid * Cin, hid * Cin, _p(P1), 1.0, 0, _stream())
             else:

@@ -533,6 +533,7 @@ def finish_backward() -> None:
     across steps."""
     if torch._C._current_graph_task_id() >= 0:
         return  # still inside a backward pass: its own callback will run
+    _bwd_handover.clear()
     if _pending_by_task:
         # callbacks that never ran (backward raised): the queued reductions belong to void backward passes — drop them, re-join the stream
         _pending_by_task.clear()
@@ -701,21 +702,53 @@ def gram_of_input(x, C, training):
     return None
 
 
-def _bn_backward_coeffs(y, dout, stats, gamma, act, rows, C, training, beta=None):
+# Gradient statistics handed BACKWARD from the kernel that produces a block's incoming gradient to that block's BatchNorm backward
+# (CVH_BN_HANDOVER=0 switches it off): key = address of the gradient tensor -> (partial rows [R][2][C] of (sum dX, sum dX * x), R, C, rows, address and
+# version of x at the producer's forward).  Entries are consumed by the first lookup and dropped at the end of every backward pass.
+_BN_HANDOVER = os.environ.get("CVH_BN_HANDOVER", "1") == "1"
+_bwd_handover = {}
+
+
+def offer_grad_stats(dx, part, R, C, rows, x):
+    if len(_bwd_handover) > 64:  # offers nobody took (their consumer is not a fused block): never more than a step's worth
+        _bwd_handover.clear()
+    _bwd_handover[dx.data_ptr()] = (part, int(R), int(C), int(rows), x.data_ptr(), x._version)
+
+
+def take_grad_stats(dout, C, rows, out_ptr, out_version):
+    h = _bwd_handover.pop(dout.data_ptr(), None)
+    if h is None:
+        return None
+    part, R, hc, hrows, xptr, xver = h
+    if hc != C or hrows != rows or xptr != out_ptr or xver != out_version:
+        return None
+    return part, R
+
+
+def _bn_backward_coeffs(y, dout, stats, gamma, act, rows, C, training, beta=None, handed=None):
     """The statistics half of the BatchNorm backward: returns (coeff[3][C], dgamma, dbeta) with dy_raw = coeff[0] * (dout * act'(bn(y))) +
-    coeff[1] * y + coeff[2] left to the consumer (cvh_bn_bwd_apply, or an operand load that forms it: csrc/ir_pb.hip)."""
+    coeff[1] * y + coeff[2] left to the consumer (cvh_bn_bwd_apply, or an operand load that forms it: csrc/ir_pb.hip).
+    handed = (part, R): partial rows (sum dout, sum dout * OUT) formed by the kernel that wrote dout (cvh_ir_exp_bwd_s), OUT being this
+    BatchNorm's own stored output — no pass over (dout, y) here."""
     dev = y.device
-    R = _lib.query("cvh_colreduce_rows", rows, C)
-    part = _f32(R * 2 * C, dev)
-    _lib.call("cvh_bn_bwd_reduce", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), act, rows, C, _p(part),
-              _stream())
+    if handed is None:
+        R = _lib.query("cvh_colreduce_rows", rows, C)
+        part = _f32(R * 2 * C, dev)
+        _lib.call("cvh_bn_bwd_reduce", _dt(y), _p(y), _p(dout), _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), act, rows, C, _p(part),
+                  _stream())
+    else:
+        part, R = handed
     sg, sb = _grad_sink(gamma), _grad_sink(beta)
     inplace = sg is not None and sb is not None
     dgamma = sg if inplace else _f32(C, dev)
     dbeta = sb if inplace else _f32(C, dev)
     coeff = _f32(3, dev, C)
-    _lib.call("cvh_bn_bwd_finalize", _p(part), R, C, float(rows), _p(gamma), _p(stats[0]), _p(stats[1]), 1 if training else 0,
-              1 if inplace else 0, _p(dgamma), _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
+    if handed is None:
+        _lib.call("cvh_bn_bwd_finalize", _p(part), R, C, float(rows), _p(gamma), _p(stats[0]), _p(stats[1]), 1 if training else 0,
+                  1 if inplace else 0, _p(dgamma), _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
+    else:
+        _lib.call("cvh_bn_bwd_finalize_out", _p(part), R, C, float(rows), _p(gamma), _p(beta), _p(stats[0]), _p(stats[1]), 1 if training else 0,
+                  1 if inplace else 0, _p(dgamma), _p(dbeta), _p(coeff[0]), _p(coeff[1]), _p(coeff[2]), _stream())
     if inplace:
         dgamma = dbeta = None
     return coeff, dgamma, dbeta

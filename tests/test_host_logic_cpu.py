@@ -238,3 +238,48 @@ def test_temporal_block_host_composition_against_the_oracle(monkeypatch):
         want = torch.autograd.grad((fm_o * g).sum() + (p_o * gp).sum(), ins_o)
         for a, w in zip(got, want):
             assert torch.allclose(a, w, rtol=1e-3, atol=1e-5), (H, W, T)
+
+
+def test_gradient_statistics_handover_is_keyed_and_validated():
+    """ops.offer_grad_stats / take_grad_stats (the backward hand-over of DESIGN.md section 4a'''): statistics are taken only for the very
+    gradient tensor they were formed on, only against the output tensor (address and version) they were formed with, and only once."""
+    import torch
+    from cvnets_amd import ops
+
+    ops._bwd_handover.clear()
+    dx, x, part = torch.zeros(8, 4), torch.zeros(8, 4), torch.zeros(3 * 2 * 4)
+    ops.offer_grad_stats(dx, part, 3, 4, 8, x)
+    assert ops.take_grad_stats(torch.zeros(8, 4), 4, 8, x.data_ptr(), x._version) is None          # another gradient tensor
+    ops.offer_grad_stats(dx, part, 3, 4, 8, x)
+    assert ops.take_grad_stats(dx, 4, 8, torch.zeros(8, 4).data_ptr(), 0) is None                  # formed against another output tensor
+    assert ops.take_grad_stats(dx, 4, 8, x.data_ptr(), x._version) is None                         # ... and an offer is consumed by the first lookup
+    ops.offer_grad_stats(dx, part, 3, 4, 8, x)
+    x.add_(1.0)                                                                                     # the output was modified in place since
+    assert ops.take_grad_stats(dx, 4, 8, x.data_ptr(), x._version) is None
+    ops.offer_grad_stats(dx, part, 3, 4, 8, x)
+    assert ops.take_grad_stats(dx, 8, 8, x.data_ptr(), x._version) is None                         # another width
+    ops.offer_grad_stats(dx, part, 3, 4, 8, x)
+    got = ops.take_grad_stats(dx, 4, 8, x.data_ptr(), x._version)
+    assert got is not None and got[0] is part and got[1] == 3
+    for i in range(70):                                                                             # offers nobody takes do not pile up
+        ops.offer_grad_stats(torch.zeros(1), part, 3, 4, 8, x)
+    assert len(ops._bwd_handover) <= 65
+    ops.finish_backward()
+    assert not ops._bwd_handover
+
+
+def test_mobilevitv2_patch_fold_and_unfold_follow_the_reference_layout():
+    """MobileViTBlockv2._unfold / _fold (the [B, C, P, N] patches the temporal path returns and takes) against the reference's
+    unfolding_pytorch / folding_pytorch formulas (cvnets/modules/mobilevit_block.py:526-555: F.unfold / F.fold with kernel = stride = patch)."""
+    import torch
+    import torch.nn.functional as F
+    from cvnets_amd.layers import default_opts
+    from cvnets_amd.modules import MobileViTBlockv2
+
+    for ph, pw, H, W in ((2, 2, 8, 12), (4, 2, 8, 6)):
+        blk = MobileViTBlockv2(default_opts(), in_channels=16, attn_unit_dim=32, n_attn_blocks=1, patch_h=ph, patch_w=pw)
+        fm = torch.randn(2, 32, H, W)
+        ref = F.unfold(fm, kernel_size=(ph, pw), stride=(ph, pw)).reshape(2, 32, ph * pw, -1)
+        assert torch.equal(blk._unfold(fm), ref)
+        back = F.fold(ref.reshape(2, 32 * ph * pw, -1), output_size=(H, W), kernel_size=(ph, pw), stride=(ph, pw))
+        assert torch.equal(blk._fold(ref, H, W), back) and torch.equal(back, fm)

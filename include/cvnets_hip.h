@@ -32,6 +32,13 @@ extern "C" {
 #define CVH_ACT_SILU 1 /* nn.SiLU  — cvnets/layers/activation/swish.py */
 #define CVH_ACT_GELU 2 /* nn.GELU (erf) — cvnets/layers/activation/gelu.py:11-18 */
 #define CVH_ACT_RELU 3 /* nn.ReLU — cvnets/layers/activation/relu.py (segmentation heads: model.activation.name = relu) */
+/* FFN pairing with a STORED derivative (transformer-sized hidden widths; cvnets/modules/transformer.py:140-155): a forward GEMM called with
+ * act = CVH_ACT_GELU_D applies GELU and writes GELU'(pre-activation) - not the pre-activation - to save_pre (cvh_conv_gemm on the
+ * large-tile kernels only: -2 elsewhere); a backward GEMM called with actgrad_act = CVH_ACT_DERIV multiplies by actgrad_aux as it is.
+ * The erf / exp of the derivative are then evaluated once, in the forward epilogue that needs them anyway, and the separate
+ * activation-backward pass over the 4x-wide hidden gradient becomes one multiply in the dX GEMM's epilogue. */
+#define CVH_ACT_DERIV 17
+#define CVH_ACT_GELU_D 18
 
 /* ---- layout / dtype plumbing ------------------------------------------------------------------ */
 /* NCHW float32 -> NHWC `dtype`, channels zero-padded to Cp (Cp % 8 == 0).  Replaces the implicit
@@ -63,6 +70,8 @@ int cvh_cast_to_f32(int dtype, const void* in, float* out, long long n, void* st
  * (cvnets/layers/linear_layer.py:90), torch.cat before the fusion conv (cvnets/modules/mobilevit_block.py:287),
  * the activation / dropout / residual that follow (cvnets/modules/transformer.py:140-155), and — with the
  * mode-1 weight pack — their dX backward. */
+/* 1: cvh_conv_gemm(bf16, plain linear [M x K] x [N x K]^T) accepts act = CVH_ACT_GELU_D (a kernel with the stored-derivative epilogue runs) */
+int cvh_conv_gemm_takes_gelu_d(long long M, int K, int N);
 int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2, const void* wgt, void* out,
                   int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
                   const float* bias, int act, void* save_pre, const void* actgrad_aux, int actgrad_act,

@@ -14,6 +14,8 @@
 #define CVH_ACT_SILU 1
 #define CVH_ACT_GELU 2
 #define CVH_ACT_RELU 3
+#define CVH_ACT_DERIV 17   /* backward: multiply by a stored derivative (include/cvnets_hip.h) */
+#define CVH_ACT_GELU_D 18  /* forward: GELU that stores its derivative */
 
 struct bf16_t {
   uint16_t v;
@@ -198,6 +200,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {  // d act(x) / dx
     return cdf + x * pdf;
   }
   if (act == CVH_ACT_RELU) return x > 0.0f ? 1.0f : 0.0f;
+  if (act == CVH_ACT_DERIV) return x;  // x IS the stored derivative
   return 1.0f;
 }
 // 8-wide forms: ONE (wave-uniform) dispatch on `act` per vector instead of one per element — the per-element scalar branches
@@ -206,12 +209,23 @@ __device__ __forceinline__ void act_fwd8(float* v, int act) {
   if (act == CVH_ACT_SILU) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = v[j] * sigmoidf_(v[j]);
-  } else if (act == CVH_ACT_GELU) {
+  } else if (act == CVH_ACT_GELU || act == CVH_ACT_GELU_D) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
   } else if (act == CVH_ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+  }
+}
+// v[j] = GELU(x[j]) and d[j] = GELU'(x[j]) from one erf (CVH_ACT_GELU_D: the derivative is stored for the backward GEMM's epilogue)
+__device__ __forceinline__ void gelu_fwd_deriv8(float* v, float* d) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j];
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * fast_exp(-0.5f * x * x);
+    v[j] = x * cdf;
+    d[j] = cdf + x * pdf;
   }
 }
 // g[j] *= act'(x[j])
@@ -232,6 +246,9 @@ __device__ __forceinline__ void act_grad8_mul(float* g, const float* x, int act)
   } else if (act == CVH_ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = x[j] > 0.0f ? g[j] : 0.0f;
+  } else if (act == CVH_ACT_DERIV) {  // x already holds act'(pre-activation) (stored by a CVH_ACT_GELU_D forward)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= x[j];
   }
 }
 

@@ -92,6 +92,21 @@ extern "C" int cvh_conv_gemm_grid_rows(int M, int N) {
   return mt < cap ? mt : cap;
 }
 
+/* 1: a plain linear of these sizes, called with act = CVH_ACT_GELU_D, runs on a kernel that stores the derivative (bf16 only) */
+extern "C" int cvh_conv_gemm_takes_gelu_d(long long M, int K, int N) {
+  ConvGemmParams p;
+  p.src1 = nullptr; p.src2 = nullptr; p.C1 = K; p.C2 = 0; p.wgt = nullptr; p.out = nullptr;
+  p.B = 1; p.H = 1; p.W = (int)M; p.Ho = 1; p.Wo = (int)M; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.M = (int)M; p.N = N; p.Ktot = K;
+  p.bias = nullptr; p.act = CVH_ACT_GELU_D; p.save_pre = nullptr; p.actgrad_aux = nullptr; p.actgrad_act = 0;
+  p.residual = nullptr; p.drop_p = 0.f; p.seed = nullptr; p.stream_id = 0; p.stats_part = nullptr;
+  p.m_tiles = 0;
+  conv_gemm_params_no_fx(p);
+  p.sc_s = 0; p.sc_KW = p.sc_C = p.sc_H = p.sc_W = p.sc_Ho = p.sc_Wo = 0;
+  if (M <= 0 || M > 0x7fffffffLL || (K % 8) || (N % 8)) return 0;
+  return (!gemm_stream_eligible(p) && gemm_big_eligible(p)) ? 1 : 0;
+}
+
 extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int C1, int C2, const void* wgt, void* out,
                              int B, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int N,
                              const float* bias, int act, void* save_pre, const void* actgrad_aux, int actgrad_act,
@@ -110,6 +125,10 @@ extern "C" int cvh_conv_gemm(int dtype, const void* src1, const void* src2, int 
   p.sc_s = 0; p.sc_KW = p.sc_C = p.sc_H = p.sc_W = p.sc_Ho = p.sc_Wo = 0;
   if (p.M <= 0 || N <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (act == CVH_ACT_GELU_D) {  // the stored-derivative epilogue exists in the large-tile kernels only (the caller checks cvh_conv_gemm_takes_gelu_d)
+    if (dtype != CVH_DT_BF16 || gemm_stream_eligible(p) || !gemm_big_eligible(p)) return -2;
+    return launch_gemm_big(p, st);
+  }
   if (dtype == CVH_DT_BF16 && conv3x3_eligible(p)) return launch_conv3x3(p, cvh_conv_gemm_grid_rows(p.M, N), st);  // MobileViT-block 3x3 convs
   if (dtype == CVH_DT_BF16 && gemm_stream_eligible(p)) return launch_gemm_stream(p, st);  // short-K token linears / 1x1 convs (MobileViT blocks)
   if (dtype == CVH_DT_BF16 && gemm_big_eligible(p)) return launch_gemm_big(p, st);  // transformer-sized linears (ViT-B / CLIP)

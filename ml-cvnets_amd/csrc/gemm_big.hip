@@ -163,10 +163,20 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt128_kernel(C
     if (m < M && (!RAGGED || ncol < N)) {
       const size_t o = (size_t)m * N + ncol;
       V8<bf16_t> pv = v8_load<bf16_t>(stg + row * STG_PITCH + ch * 8);
-      if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
       float v[8];
       v8_unpack(pv, v);
-      if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
+      if (p.act == CVH_ACT_GELU_D) {  // GELU, and GELU'(pre) instead of pre for the backward GEMM's epilogue (cvnets_hip.h)
+        float d[8];
+        gelu_fwd_deriv8(v, d);
+        if (p.save_pre) {
+          V8<bf16_t> dv;
+          v8_pack(d, dv);
+          v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, dv);
+        }
+      } else {
+        if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
+        if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
+      }
       if (p.actgrad_aux) {  // backward through the producer's activation: v *= act'(pre-activation of the layer below)
         float a[8];
         v8_unpack(agr[pass], a);
@@ -309,10 +319,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(ConvGemmParams p) {
       if (m < M) {
         const size_t o = (size_t)m * N + ncol;
         V8<bf16_t> pv = v8_load<bf16_t>(stg + row * STG_PITCH + ch * 8);
-        if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
         float v[8];
         v8_unpack(pv, v);
-        if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
+        if (p.act == CVH_ACT_GELU_D) {  // GELU, and GELU'(pre) instead of pre for the backward GEMM's epilogue (cvnets_hip.h)
+          float d[8];
+          gelu_fwd_deriv8(v, d);
+          if (p.save_pre) {
+            V8<bf16_t> dv;
+            v8_pack(d, dv);
+            v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, dv);
+          }
+        } else {
+          if (p.save_pre) v8_store<bf16_t>(reinterpret_cast<bf16_t*>(p.save_pre) + o, pv);
+          if (p.act != CVH_ACT_NONE) act_fwd8(v, p.act);
+        }
         if (p.actgrad_aux) {
           float a[8];
           v8_unpack(agr[pass], a);

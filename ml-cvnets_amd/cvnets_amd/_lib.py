@@ -30,6 +30,7 @@ SIGNATURES = {
     "cvh_cast_from_f32": [I, P, P, L, P],
     "cvh_cast_to_f32": [I, P, P, L, P],
     "cvh_conv_gemm": [I, P, P, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, I, P, P, I, P, F, P, U, P, P],
+    "cvh_conv_gemm_takes_gelu_d": [L, I, I],
     "cvh_conv_gemm_grid_rows": [I, I],
     "cvh_stream_counters": [I, P],  # out = long long[4]
     "cvh_family_counters": [I, I, P],  # out = long long[2]

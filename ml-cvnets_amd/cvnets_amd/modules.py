@@ -189,9 +189,13 @@ class TransformerEncoder(nn.Module):
         if pf > 0.0:
             h = ops.dropout(ops.linear(y, fc1.weight, fc1.bias, act=a), pf, True)
             return ops.linear(h, fc2.weight, fc2.bias, drop_p=p2, residual=x)
+        if _FUSED_FFN_BWD and fc1.out_features >= 1024 and ops.ffn_stores_derivative(y, fc1.weight, a):
+            # transformer-sized FFNs (ViT-B: 3072 hidden): fc1's epilogue evaluates erf / exp once and stores GELU'(pre) instead of the
+            # pre-activation; fc2's dX GEMM multiplies by it - the separate activation-backward pass over the hidden gradient is gone.
+            # (With act'(pre) EVALUATED in the dX epilogue the large-tile GEMM lost 4.5 %: erf / exp serialise behind its MFMA work.)
+            h, dv = ops.linear(y, fc1.weight, fc1.bias, act=ops.ACT_GELU_D, expose_pre=True)
+            return ops.linear(h, fc2.weight, fc2.bias, drop_p=p2, residual=x, in_pre=dv, in_act=ops.ACT_DERIV)
         if not _FUSED_FFN_BWD or fc1.out_features >= 1024:
-            # transformer-sized FFNs (ViT-B: 3072 hidden): measured -4.5 % with the fusion — the erf/exp epilogue serialises behind
-            # the MFMA-bound large-tile GEMM, while the separate elementwise pass runs at HBM speed; MobileViT-sized FFNs gain ~1 %
             return ops.linear(ops.linear(y, fc1.weight, fc1.bias, act=a), fc2.weight, fc2.bias, drop_p=p2, residual=x)
         h, pre = ops.linear(y, fc1.weight, fc1.bias, act=a, expose_pre=True)
         # fc2's dX GEMM applies act'(pre) in its epilogue and returns the gradient of fc1's pre-activation directly

@@ -26,6 +26,7 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
+ACT_DERIV, ACT_GELU_D = 17, 18  # include/cvnets_hip.h: "multiply by the stored derivative" / "GELU forward that stores its derivative"
 _COMPUTE_DTYPE: Optional[torch.dtype] = None
 
 
@@ -1148,8 +1149,8 @@ class LinearAct(torch.autograd.Function):
                 if dy is None:
                     dy = torch.empty_like(dout)
                     _lib.call("cvh_dropout", _dt(dout), _p(dout), _p(dy), rows * N, float(drop_p), _p(ctx.seed), stream_id, _stream())
-            if act != ACT_NONE:
-                dy = _act_backward(pre, dy, act, rows, N)
+            if act != ACT_NONE:  # (ACT_GELU_D: `pre` holds GELU'(pre-activation) - one multiply)
+                dy = _act_backward(pre, dy, ACT_DERIV if act == ACT_GELU_D else act, rows, N)
             if expose_pre and dpre is not None:
                 dy = add(dy, dpre.contiguous())
         dbias = None
@@ -1173,6 +1174,14 @@ class LinearAct(torch.autograd.Function):
                 _conv_gemm(dy, None, N, 0, wpt, dx, rows, 1, 1, 1, 1, 1, 1, 1, 0, 1, K)
         dres = dout if (ctx.has_res and dout is not None) else None
         return dx, dw_ret, dbias, dres, d_in_pre, None
+
+
+def ffn_stores_derivative(x2d, weight, act) -> bool:
+    """transformer-sized FFN (ViT-B / CLIP: 768 -> 3072): fc1 stores GELU'(pre) instead of the pre-activation and fc2's dX GEMM multiplies by
+    it in its epilogue (ACT_GELU_D / ACT_DERIV) - where the large-tile kernel with that epilogue takes the product"""
+    if act != ACT_GELU or x2d.dtype != torch.bfloat16 or not x2d.is_cuda:
+        return False
+    return _lib.query("cvh_conv_gemm_takes_gelu_d", x2d.shape[0], x2d.shape[1], weight.shape[0]) == 1
 
 
 def linear(x2d, weight, bias=None, *, act=ACT_NONE, drop_p=0.0, residual=None, expose_pre=False, in_pre=None, in_act=ACT_NONE):

@@ -292,6 +292,70 @@ __device__ __forceinline__ void dropout_scale8(const DropKey& k, uint64_t idx8, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS transpose reads next to direct-to-LDS loads.  With __builtin_amdgcn_ds_read_tr16_b64_* the compiler cannot tell which LDS bytes the
+// read touches, so while ANY global_load_lds of the wave is outstanding it puts `s_waitcnt vmcnt(0)` in front of every such read: a kernel
+// that requests the next reduction step's tiles and then reads the current ones waits for the NEXT step to land before its first MFMA (found
+// in round 6 in every dW kernel: gemm_tn128 / gemm_tn256 / gemm_tn_rows ran load -> wait -> compute with no overlap at all).  These forms
+// issue the same instruction from inline asm: the compiler places no wait, the kernel orders the data itself - tr_wait() before the first
+// use of the fragments (it names them, so the MFMAs cannot be scheduled above it), the kernel's own vmcnt + barrier before a buffer is read.
+// ---------------------------------------------------------------------------------------------
+#ifndef CVH_TR_ASM
+#define CVH_TR_ASM 1  // 0 (tools/build_variant.py): the builtin form, for A/B runs
+#endif
+typedef short cvh_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+template <int OFF> __device__ __forceinline__ cvh_v4s ds_read_tr16_b64_raw(unsigned addr) {
+#if CVH_TR_ASM
+  cvh_v4s r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+#else
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cvh_v4s*)(size_t)(addr + OFF));
+#endif
+}
+// one MFMA operand (8 reduction elements per lane) from two transpose reads HI bytes apart
+template <int HI> __device__ __forceinline__ bf16x8_t tr_frag_raw(unsigned addr) {
+  const cvh_v4s lo = ds_read_tr16_b64_raw<0>(addr), hi = ds_read_tr16_b64_raw<HI>(addr);
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <int HI> __device__ __forceinline__ bf16x8_t tr_frag_raw2(unsigned addr, unsigned hi_off) {  // run-time distance between the two reads
+  const cvh_v4s lo = ds_read_tr16_b64_raw<0>(addr), hi = ds_read_tr16_b64_raw<HI>(addr + hi_off);
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// 16 plain bytes of an LDS image that direct-to-LDS loads are filling elsewhere (same reason, same contract: tr_wait1 before use)
+typedef unsigned cvh_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cvh_u32x4 lds_read_b128_raw(unsigned addr) {
+#if CVH_TR_ASM
+  cvh_u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+#else
+  return *(__attribute__((address_space(3))) const cvh_u32x4*)(size_t)addr;
+#endif
+}
+__device__ __forceinline__ void tr_wait1(cvh_u32x4& a) {
+#if CVH_TR_ASM
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
+#endif
+}
+__device__ __forceinline__ void tr_wait1(bf16x8_t& a) {
+#if CVH_TR_ASM
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
+#endif
+}
+// every LDS read of the wave has returned; the named fragments are "produced" here
+__device__ __forceinline__ void tr_wait(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d) {
+#if CVH_TR_ASM
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
+}
+__device__ __forceinline__ void tr_wait(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d, bf16x8_t& e, bf16x8_t& f) {
+#if CVH_TR_ASM
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -417,10 +417,8 @@ __device__ __forceinline__ Frag<bf16_t> frag_tr(const unsigned char* img, int kk
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
   const int r = 8 * (lane >> 5) + (i >> 2);
   const unsigned char* p = img + (kk * 4 + (col >> 5)) * 1024 + r * 64 + (col & 31) * 2;
-  const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
-  const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + 4 * 64));
   Frag<bf16_t> f;
-  f.v = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  f.v = tr_frag_raw<4 * 64>(lds_addr32(p));  // inline-asm form (common.hpp): no compiler-placed vmcnt(0) in front of it; the caller runs tr_wait()
   return f;
 }
 }  // namespace
@@ -491,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
       Frag<bf16_t> a1 = frag_tr(Yt, kk, wave_n * 64 + 32, lane);
       Frag<bf16_t> b0 = frag_tr(Xt, kk, wave_k * 64, lane);
       Frag<bf16_t> b1 = frag_tr(Xt, kk, wave_k * 64 + 32, lane);
+      tr_wait(a0.v, a1.v, b0.v, b1.v);
       mma32(acc[0][0], a0, b0);
       mma32(acc[0][1], a0, b1);
       mma32(acc[1][0], a1, b0);
@@ -536,10 +535,8 @@ __device__ __forceinline__ Frag<bf16_t> frag_tr256(const unsigned char* img, int
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
   const int r = 8 * (lane >> 5) + (i >> 2);
   const unsigned char* p = img + (kk * 8 + (col >> 5)) * 1024 + r * 64 + (col & 31) * 2;
-  const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p));
-  const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_v4s*)(p + 4 * 64));
   Frag<bf16_t> f;
-  f.v = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  f.v = tr_frag_raw<4 * 64>(lds_addr32(p));  // the caller runs tr_wait() before the first MFMA
   return f;
 }
 
@@ -613,7 +610,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         V8<bf16_t> v;
-        v.d = *reinterpret_cast<const uint4*>(Yt + q * 8 * 1024 + cs_off);
+        cvh_u32x4 raw = lds_read_b128_raw(lds_addr32(Yt + q * 8 * 1024 + cs_off));  // (a plain load here draws a compiler-placed vmcnt(0): common.hpp)
+        tr_wait1(raw);
+        v.d = __builtin_bit_cast(uint4, raw);
         float f[8];
         v8_unpack(v, f);
 #pragma unroll
@@ -622,13 +621,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const Frag<bf16_t> a0 = frag_tr256(Yt, kk, wave_n * 64, lane);
-      const Frag<bf16_t> a1 = frag_tr256(Yt, kk, wave_n * 64 + 32, lane);
+      Frag<bf16_t> a0 = frag_tr256(Yt, kk, wave_n * 64, lane);
+      Frag<bf16_t> a1 = frag_tr256(Yt, kk, wave_n * 64 + 32, lane);
+      Frag<bf16_t> b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = frag_tr256(Xt, kk, wave_k * 128 + 32 * j, lane);
+      tr_wait(a0.v, a1.v, b[0].v, b[1].v, b[2].v, b[3].v);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const Frag<bf16_t> b = frag_tr256(Xt, kk, wave_k * 128 + 32 * j, lane);
-        mma32(acc[0][j], a0, b);
-        mma32(acc[1][j], a1, b);
+        mma32(acc[0][j], a0, b[j]);
+        mma32(acc[1][j], a1, b[j]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -36,6 +36,12 @@ __device__ __forceinline__ void gr_glds16(const void* g, unsigned char* l) { __b
 // inline-asm transpose reads (common.hpp: the builtin form draws a compiler-placed s_waitcnt vmcnt(0) in front of every read while direct-to-LDS
 // loads are outstanding - this kernel keeps three stages of them in flight by design); the caller runs tr_wait1() on the fragment before its first MFMA
 __device__ __forceinline__ bf16x8_t gr_tr_frag(const unsigned char* lo, int hi_off) { return tr_frag_raw2<0>(lds_addr32(lo), (unsigned)hi_off); }
+// the builtin form (draws the compiler's vmcnt(0)): kept for the 4 x 4 rectangle, where the asm form's address registers spill
+__device__ __forceinline__ bf16x8_t gr_tr_frag_builtin(const unsigned char* lo, int hi_off) {
+  const gr_v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gr_v4s*)(lo));
+  const gr_v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gr_v4s*)(lo + hi_off));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 template <int N> __device__ __forceinline__ void gr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -126,8 +132,40 @@ __global__ __launch_bounds__(64 * GR_WAVES) void gemm_tn_rows_kernel(GemmTNParam
     wg_barrier_lds();  // every wave's pieces of stage st have landed; every wave is done with stage st - 1, whose buffer is refilled now
     if (st + GR_NSTAGE - 1 < nsteps) issue(st + GR_NSTAGE - 1);
     const unsigned char* img = smem + (st & (GR_NSTAGE - 1)) * g.stage_bytes;
-    // every LDS read of the stage is issued up front (inline-asm forms, common.hpp: no compiler-placed vmcnt(0) in front of them), one wait, then
-    // the MFMAs: the LDS latency is paid once per stage
+    if constexpr (PN * PK >= 16) {
+      // 4 x 4 rectangle: the builtin reads, one dY fragment at a time (round-5 form; 122 registers - the asm form below spills here, and a
+      // spill reload inside the loop is a vmcnt(0) of its own)
+      if (bias_thread) {
+        V8<bf16_t> v;
+        v.d = *reinterpret_cast<const uint4*>(img + bias_off);
+        float f[8];
+        v8_unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += f[j];
+      }
+      bf16x8_t bf[PK];
+      if (!(g.dbg & 1)) {
+#pragma unroll
+        for (int j = 0; j < PK; ++j) {
+          const int kb = wk * PK + j;
+          bf[j] = gr_tr_frag_builtin(img + b_off + (kb < tkb ? kb : 0) * 32, b_hi);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PN; ++i) {
+        const int nb = wn * PN + i;
+        bf16x8_t af;
+        if (!(g.dbg & 1)) af = gr_tr_frag_builtin(img + a_off + (nb < tnb ? nb : 0) * 32, a_hi);
+#pragma unroll
+        for (int j = 0; j < PK; ++j) {
+          if (!(g.dbg & 2) && nb < tnb && wk * PK + j < tkb)  // wave-uniform
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+    // every LDS read of the stage is issued up front (inline-asm forms, common.hpp: no compiler-placed vmcnt(0) in front of them) and waited
+    // for once, then the MFMAs: the LDS latency is paid once per stage
     cvh_u32x4 braw;
     if (bias_thread) braw = lds_read_b128_raw(lds_addr32(img + bias_off));
     bf16x8_t bf[PK], af[PN];
@@ -164,6 +202,7 @@ __global__ __launch_bounds__(64 * GR_WAVES) void gemm_tn_rows_kernel(GemmTNParam
         if (!(g.dbg & 2) && nb < tnb && wk * PK + j < tkb)  // wave-uniform
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);  // D[n][k] += sum_m dY[m][n] X[m][k]
       }
+    }
     }
   }
 

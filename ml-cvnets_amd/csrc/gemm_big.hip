@@ -15,6 +15,13 @@
 #include "common.hpp"
 #include "gemm_params.hpp"
 
+#ifndef CVH_TN128_GI
+#define CVH_TN128_GI 1  // the same for gemm_tn128_kernel
+#endif
+#ifndef CVH_TN_GI
+#define CVH_TN_GI 1  // gemm_tn256_kernel: 0 (tools/build_variant.py) = all eight pieces of the next step issued as a block after the barrier
+#endif
+
 namespace {
 constexpr int BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;     // 16 KB per 128-row operand tile
@@ -452,17 +459,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
   // bias gradient of the same layer (otherwise a separate pass over dY, cvh_colsum).  bf16 1.0 x dY is exact, accumulation is the MFMA's fp32.
   const bool fold_bias = RAGGED && p.bias_part != nullptr;
   const bf16_t* ones = reinterpret_cast<const bf16_t*>(g_ones_line);
-  auto issue = [&](int step, int buf) {
+  auto issue_y = [&](int step, int buf, int j) __attribute__((always_inline)) {  // piece j (of 4) of this wave's dY rows of a step
     const bool ok = m_begin + step * 64 + row_off < m_end;
     unsigned char* y_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024;
-    unsigned char* x_dst = y_dst + TILE_BYTES;
+    const bool oky = ok && (!RAGGED || n0 + j * 32 + (lane & 3) * 8 < N);
+    glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
+  };
+  auto issue_x = [&](int step, int buf, int j) __attribute__((always_inline)) {
+    const bool ok = m_begin + step * 64 + row_off < m_end;
+    unsigned char* x_dst = smem + buf * BUF_BYTES + (wave * 4) * 1024 + TILE_BYTES;
+    const int kcol = k0 + j * 32 + (lane & 3) * 8;
+    const bool okx = ok && (!RAGGED || kcol < K);
+    glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : ((fold_bias && ok && kcol == K) ? ones : zero), x_dst + j * 1024);
+  };
+  auto issue = [&](int step, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int kcol = k0 + j * 32 + (lane & 3) * 8;
-      const bool oky = ok && (!RAGGED || n0 + j * 32 + (lane & 3) * 8 < N);
-      const bool okx = ok && (!RAGGED || kcol < K);
-      glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
-      glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : ((fold_bias && ok && kcol == K) ? ones : zero), x_dst + j * 1024);
+      issue_y(step, buf, j);
+      issue_x(step, buf, j);
     }
   };
 
@@ -480,7 +494,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
   }
   for (int st = 0; st < steps; ++st) {
     const int buf = st & 1;
+#if !CVH_TN128_GI
     if (st + 1 < steps) issue(st + 1, buf ^ 1);
+#endif
+    const int stn = st + 1 < steps ? st + 1 : st;  // CVH_TN128_GI: the last step re-requests itself into the free buffer
     const unsigned char* Yt = smem + buf * BUF_BYTES;
     const unsigned char* Xt = Yt + TILE_BYTES;
 #pragma unroll
@@ -490,10 +507,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128_kernel(GemmTNParams p) {
       Frag<bf16_t> b0 = frag_tr(Xt, kk, wave_k * 64, lane);
       Frag<bf16_t> b1 = frag_tr(Xt, kk, wave_k * 64 + 32, lane);
       tr_wait(a0.v, a1.v, b0.v, b1.v);
+#if CVH_TN128_GI
+      // the next step's eight direct-to-LDS pieces go out one at a time behind the MFMAs of the first two K slices (see gemm_tn256_kernel)
+      mma32(acc[0][0], a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) issue_y(stn, buf ^ 1, 0);
+      if (kk == 1) issue_x(stn, buf ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32(acc[0][1], a0, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) issue_y(stn, buf ^ 1, 1);
+      if (kk == 1) issue_x(stn, buf ^ 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32(acc[1][0], a1, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) issue_y(stn, buf ^ 1, 2);
+      if (kk == 1) issue_x(stn, buf ^ 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32(acc[1][1], a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk == 0) issue_y(stn, buf ^ 1, 3);
+      if (kk == 1) issue_x(stn, buf ^ 1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+#else
       mma32(acc[0][0], a0, b0);
       mma32(acc[0][1], a0, b1);
       mma32(acc[1][0], a1, b0);
       mma32(acc[1][1], a1, b1);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -567,17 +608,24 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_line);
   const bool fold_bias = RAGGED && p.bias_part != nullptr && (K % 256) != 0;  // column K of the padded last k tile = a column of ones (see gemm_tn128_kernel)
   const bf16_t* ones = reinterpret_cast<const bf16_t*>(g_ones_line);
-  auto issue = [&](int step, int buf) {
+  auto issue_y = [&](int step, int buf, int j) __attribute__((always_inline)) {  // piece j (of 4) of this wave's dY rows of a step
     const bool ok = m_begin + step * 64 + row_off < m_end;
     unsigned char* y_dst = smem + buf * TN256_BUF + (ld_kk * 8 + 4 * ld_half) * 1024;
-    unsigned char* x_dst = y_dst + TN256_IMG;
+    const bool oky = ok && (!RAGGED || n0 + col_off + j * 32 < N);
+    glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
+  };
+  auto issue_x = [&](int step, int buf, int j) __attribute__((always_inline)) {
+    const bool ok = m_begin + step * 64 + row_off < m_end;
+    unsigned char* x_dst = smem + buf * TN256_BUF + (ld_kk * 8 + 4 * ld_half) * 1024 + TN256_IMG;
+    const int kcol = k0 + col_off + j * 32;
+    const bool okx = ok && (!RAGGED || kcol < K);
+    glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : ((fold_bias && ok && kcol == K) ? ones : zero), x_dst + j * 1024);
+  };
+  auto issue = [&](int step, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int kcol = k0 + col_off + j * 32;
-      const bool oky = ok && (!RAGGED || n0 + col_off + j * 32 < N);
-      const bool okx = ok && (!RAGGED || kcol < K);
-      glds16(oky ? gy + (size_t)step * 64 * N + j * 32 : zero, y_dst + j * 1024);
-      glds16(okx ? gx + (size_t)step * 64 * K + j * 32 : ((fold_bias && ok && kcol == K) ? ones : zero), x_dst + j * 1024);
+      issue_y(step, buf, j);
+      issue_x(step, buf, j);
     }
   };
 
@@ -603,7 +651,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
   }
   for (int st = 0; st < steps; ++st) {
     const int buf = st & 1;
+#if !CVH_TN_GI
     if (st + 1 < steps) issue(st + 1, buf ^ 1);
+#endif
+    const int stn = st + 1 < steps ? st + 1 : st;  // CVH_TN_GI: the last step re-requests itself into the free buffer (no branch in the body)
     const unsigned char* Yt = smem + buf * TN256_BUF;
     const unsigned char* Xt = Yt + TN256_IMG;
     if (colsum) {  // rows past the end of the split were fetched from the zero line
@@ -631,6 +682,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn256_kernel(GemmTNParams p) {
       for (int j = 0; j < 4; ++j) {
         mma32(acc[0][j], a0, b[j]);
         mma32(acc[1][j], a1, b[j]);
+#if CVH_TN_GI
+        // the next step's eight direct-to-LDS pieces go out one at a time between the MFMA pairs of the first two K slices
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0) issue_y(stn, buf ^ 1, j);
+        if (kk == 1) issue_x(stn, buf ^ 1, j);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
